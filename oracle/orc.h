@@ -1,0 +1,191 @@
+/*
+ * orc.h — CPU ORACLE for the stereo-VO per-frame front end.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load the library built from this directory.  The
+ * product path (stereo_visual_odometry_amd/csrc) never includes, links or calls it.
+ *
+ * What it is: a plain-C restatement of the reference pipeline
+ *   /root/reference/src/vo.cpp, /root/reference/src/feature_set.cpp, /root/reference/include/vo.h
+ * and of the OpenCV 4.5.x functions that pipeline calls (cv::FAST, cv::buildOpticalFlowPyramid,
+ * cv::calcOpticalFlowPyrLK, cv::triangulatePoints, cv::convertPointsFromHomogeneous,
+ * cv::solvePnPRansac, cv::Rodrigues).  OpenCV is a third-party dependency that is NOT vendored
+ * in the reference and NOT present in this image (the reference links libopencv_*.so.405, i.e.
+ * OpenCV 4.5.x, unpinned by any manifest: Makefile:4 uses pkg-config opencv4).  Its published
+ * algorithms are restated here from the OpenCV 4.5 documentation / sources as known; every
+ * function cites the reference call site it stands in for.
+ *
+ * Parity pin status (see DESIGN.md "Oracle"):
+ *   - Bucket / FeatureSet logic, findClosePoints: pinned by the reference's own known-answer
+ *     tests (src/main.cpp:50-78, 102-172), restated in tests/test_oracle_kat.py.
+ *   - FAST-9/16 + NMS: pinned by test_featureset (src/main.cpp:102-127): 11 features, strength<=128.
+ *   - pyramid + LK + circular mask: pinned by test_circularMatching (src/main.cpp:174-209): 121/121.
+ *   - RANSAC-PnP + LM refine: pinned by test_cameraToWorld (src/main.cpp:211-264): R,t to 1e-8/1e-6.
+ *   - Bit-level equality with OpenCV for LK / PnP / triangulation: PARITY UNPINNED (no OpenCV
+ *     here, the reference binary cannot run, and no reference test covers triangulatePoints).
+ *
+ * Deliberate, documented deviations from OpenCV numerics (all inside the pose tolerance):
+ *   D1. LK accumulates A11,A12,A22,b1,b2 as exact int64 sums and converts to float once
+ *       (OpenCV: float accumulation in SIMD-lane order, which is not reproducible).  This makes
+ *       the validity masks bit-reproducible between this oracle and the HIP kernels.
+ *   D2. The final LM refine of solvePnPRansac starts from the best RANSAC model (OpenCV 4.5:
+ *       from whichever hypothesis was evaluated last, because rvec/tvec alias the callback's
+ *       buffers).
+ *   D3. EPnP takes the null-space basis of MtM from the right singular vectors of a one-sided
+ *       Jacobi SVD (OpenCV: left singular vectors of the same decomposition, or LAPACK when
+ *       built with it) — same subspace.
+ *   D4. RANSAC hypotheses are scored with the EPnP rotation matrix directly instead of the
+ *       R -> rvec -> R round trip through cv::Rodrigues (identity up to 1 ulp); this keeps the
+ *       inlier masks free of libm (sin/cos/acos) and therefore bit-reproducible on the GPU.
+ */
+#ifndef ORC_H
+#define ORC_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LEVELS 8
+
+/* ---- configuration: the reference's compile-time constants (include/vo.h:53-127,251-252) ---- */
+typedef struct {
+    int bucket_start_row;        /* vo.h:53  = 4   */
+    int buckets_along_height;    /* vo.h:60  = 92  */
+    int buckets_along_width;     /* vo.h:61  = 160 */
+    int features_per_bucket;     /* vo.h:65  = 1   */
+    int features_threshold;      /* vo.h:71  = 15  */
+    int pre_matching_feature_threshold; /* vo.h:78 = 100 */
+    int age_threshold;           /* vo.h:84  = 20  */
+    int fast_threshold;          /* vo.h:90  = 20  */
+    float ransac_reprojection_error; /* vo.h:97 = 8 */
+    int ransac_iterations;       /* vo.h:102 = 100 */
+    double optical_flow_min_eig_threshold; /* vo.h:108 = 0.001 */
+    double circular_matching_success_threshold; /* vo.h:115 = 0.15 */
+    double max_translation_norm; /* vo.h:121 = 0.1 */
+    double max_rotation_norm;    /* vo.h:127 = 0.5 */
+    int win_w, win_h;            /* vo.h:251 = 10,10 */
+    int max_level;               /* vo.h:252 = 3 */
+    int lk_max_count;            /* vo.cpp:183 = 30 */
+    double lk_epsilon;           /* vo.cpp:184 = 1e-4 */
+    float ransac_confidence;     /* vo.cpp:295 = 0.98f (a float32 in the reference) */
+    int max_features;            /* build preset, NOT in the reference: 0 = unlimited; >0 keeps the
+                                    first max_features of the bucketed set */
+} orc_config;
+
+void orc_config_default(orc_config* c);
+
+/* ---- FAST-9/16 (cv::FAST, called at feature_set.cpp:61) ---- */
+/* Writes NMS-surviving corner scores (0 elsewhere) into score[h*w]. nonmax=0 writes raw corner flags as score. */
+void orc_fast_score_map(const uint8_t* img, int w, int h, int stride, int threshold, int nonmax, uint8_t* score);
+/* Raster-ordered keypoints like cv::FAST + KeyPoint::convert (feature_set.cpp:55-68).
+   xy = 2*cap floats, resp = cap floats. Returns the TOTAL count (may exceed cap; only cap are written). */
+int orc_fast_detect(const uint8_t* img, int w, int h, int stride, int threshold, int nonmax,
+                    int cap, float* xy, float* resp);
+
+/* ---- Bucket / FeatureSet (feature_set.cpp:1-152) ---- */
+typedef struct {
+    int max_size, n;
+    float* xy; int* ages; int* strengths;   /* capacity max_size */
+} orc_bucket;
+void orc_bucket_init(orc_bucket* b, int max_size);
+void orc_bucket_free(orc_bucket* b);
+int  orc_bucket_compute_score(int age, int strength, int fast_threshold);   /* feature_set.cpp:16-18 */
+void orc_bucket_add_feature(orc_bucket* b, float x, float y, int age, int strength,
+                            int age_threshold, int fast_threshold);        /* feature_set.cpp:20-53 */
+/* FeatureSet::filterByBucketLocationInternal (feature_set.cpp:95-147). In place; returns new n. */
+int orc_bucket_filter(int img_w, int img_h, int n, float* xy, int* ages, int* strengths,
+                      int buckets_along_height, int buckets_along_width, int bucket_start_row,
+                      int features_per_bucket, int age_threshold, int fast_threshold);
+
+/* ---- pyramid (cv::buildOpticalFlowPyramid, vo.cpp:50,52,200,201) ---- */
+typedef struct {
+    int nlevels;                 /* levels actually built */
+    int pad_x, pad_y;            /* = winSize */
+    int w[ORC_MAX_LEVELS], h[ORC_MAX_LEVELS];
+    uint8_t* img[ORC_MAX_LEVELS];   int img_stride[ORC_MAX_LEVELS];    /* pointer to pixel (0,0) of a padded buffer */
+    int16_t* deriv[ORC_MAX_LEVELS]; int deriv_stride[ORC_MAX_LEVELS];  /* int16 units; interleaved (dx,dy) */
+    void* owned[2 * ORC_MAX_LEVELS];
+} orc_pyramid;
+void orc_pyr_down(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dstride); /* dst is ((sw+1)/2,(sh+1)/2) */
+void orc_scharr(const uint8_t* src, int w, int h, int sstride, int16_t* dst, int dstride);       /* calcSharrDeriv */
+void orc_build_pyramid(const uint8_t* img, int w, int h, int stride, int win_w, int win_h, int max_level, orc_pyramid* out);
+void orc_pyramid_free(orc_pyramid* p);
+
+/* ---- pyramidal LK (cv::calcOpticalFlowPyrLK, vo.cpp:203-215) ---- */
+void orc_lk_track(const orc_pyramid* prev, const orc_pyramid* next, int n, const float* prev_pts,
+                  float* next_pts, uint8_t* status, int win_w, int win_h, int max_level,
+                  int max_count, double epsilon, double min_eig_threshold);
+
+/* ---- helpers (vo.cpp:144-168, 265-280) ---- */
+void orc_find_close_points(int n, const float* p1, const float* p2, float threshold, uint8_t* ok);
+
+/* ---- circularMatching (vo.cpp:169-240) on prebuilt pyramids; returns the mask, no compaction ---- */
+void orc_circular_match(const orc_pyramid* l0, const orc_pyramid* r0, const orc_pyramid* l1, const orc_pyramid* r1,
+                        int n, const float* pl0, float* pl1, float* pr1, float* pr0, float* pl0_circle,
+                        uint8_t* ok, const orc_config* cfg);
+
+/* ---- triangulation (cv::triangulatePoints + convertPointsFromHomogeneous, vo.cpp:89-94) ---- */
+void orc_triangulate(const float Pl[12], const float Pr[12], int n, const float* pts_l, const float* pts_r,
+                     float* xyz /* 3n */, float* homog /* 4n or NULL */);
+
+/* ---- Rodrigues (cv::Rodrigues, vo.cpp:125,289,308) ---- */
+void orc_rodrigues_to_matrix(const double r[3], double R[9], double dRdr[27] /* or NULL */);
+void orc_rodrigues_to_vector(const double R[9], double r[3]);
+
+/* ---- RANSAC-PnP (cv::solvePnPRansac via cameraToWorld, vo.cpp:282-313) ---- */
+typedef struct { uint64_t state; } orc_rng;
+void     orc_rng_init(orc_rng* r, uint64_t seed);
+uint32_t orc_rng_next(orc_rng* r);
+int      orc_rng_uniform(orc_rng* r, int a, int b);
+int      orc_ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
+
+/* EPnP on n>=4 points (object f64, image pixel coords f64). K = fx,fy,cx,cy. Outputs R (row-major), t. Returns mean reproj err. */
+double orc_epnp(int n, const double* obj, const double* img, double fx, double fy, double cx, double cy,
+                double R[9], double t[3]);
+/* Levenberg–Marquardt refine as cvFindExtrinsicCameraParams2(useExtrinsicGuess=1). rvec,tvec in/out. returns iterations used */
+int orc_pnp_refine_lm(int n, const double* obj, const double* img, double fx, double fy, double cx, double cy,
+                      double rvec[3], double tvec[3]);
+/* cameraToWorld (vo.cpp:282-313). K = 3x3 f32 row-major. world = 3n f32, cam = 2n f32.
+   R (3x3 f64) and t (3 f64) are in/out (guess in, result out on success; unchanged on failure).
+   inliers: int32[n] ascending indices, *n_inliers count. Returns success (1/0).
+   dbg (optional, may be NULL): dbg[0]=iterations run, dbg[1]=best inlier count. */
+int orc_camera_to_world(const float K[9], int n, const float* cam_pts, const float* world_pts,
+                        double R[9], double t[3], int* inliers, int* n_inliers,
+                        int ransac_iterations, float reproj_error, float confidence, int* dbg);
+
+/* ---- getInverseTransform (vo.cpp:246-258) ---- */
+void orc_inverse_transform(const double R[9], const double t[3], double T[16]);
+
+/* ---- VisualOdometry (vo.cpp:41-137; state vo.h:233-269) ---- */
+typedef struct orc_vo orc_vo;
+typedef struct {
+    int n_after_detect;     /* feature-set size after appendFeaturesFromImage (vo.cpp:326 / :331) */
+    int second_pass;        /* 1 if the FAST_THRESHOLD/4 pass ran (vo.cpp:327-332) */
+    int n_into_lk;          /* after max_features cap */
+    int n_after_circular;   /* vo.cpp:239 */
+    int n_after_bounds;     /* vo.cpp:365 */
+    int n_inliers;          /* vo.cpp:103 */
+    int ransac_iters;
+    int fail_reason;        /* 0 ok, 1 first frame, 2 too few tracks, 3 ransac fail / few inliers, 4 motion gate */
+    int n_features_out;     /* size of currentVOFeatures when the callback returns */
+} orc_frame_stats;
+
+orc_vo* orc_vo_create(const orc_config* cfg);
+void    orc_vo_destroy(orc_vo* vo);
+void    orc_vo_set_projection(orc_vo* vo, const float Pl[12], const float Pr[12]);   /* vo.cpp:8-26 */
+/* returns 1 if ok (pose produced), 0 otherwise; T_out always gets the "second" of the pair (vo.cpp:43-44,136). */
+int     orc_vo_stereo_callback(orc_vo* vo, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
+                               double T_out[16], orc_frame_stats* stats);
+/* introspection for parity tests */
+int     orc_vo_num_features(const orc_vo* vo);
+void    orc_vo_get_features(const orc_vo* vo, float* xy, int* ages, int* strengths);
+void    orc_vo_get_pose_guess(const orc_vo* vo, double R[9], double t[3]);
+/* last frame's compacted tracks (after bounds mask): 4 point lists + world points + inlier flags. returns n */
+int     orc_vo_get_last_tracks(const orc_vo* vo, float* pl0, float* pr0, float* pl1, float* pr1, float* world, uint8_t* inlier);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

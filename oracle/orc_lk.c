@@ -1,0 +1,251 @@
+/* ORACLE (test infrastructure, see orc.h).  Optical-flow pyramid + pyramidal Lucas–Kanade.
+ * Stands in for cv::buildOpticalFlowPyramid (/root/reference/src/vo.cpp:50,52,200,201) and
+ * cv::calcOpticalFlowPyrLK (vo.cpp:203-215), restating OpenCV 4.5 modules/video/src/lkpyramid.cpp
+ * and modules/imgproc/src/pyramids.cpp as summarised in SURVEY.md Appendix A.2/A.3.
+ * Deviation D1 (orc.h): A and b are accumulated as exact int64 sums. */
+#include "orc.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * n - 2 - i; }
+    return i;
+}
+
+/* pyrDown, 8-bit: separable [1 4 6 4 1], (sum + 128) >> 8, source border REFLECT_101. */
+void orc_pyr_down(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dstride) {
+    int dw = (sw + 1) / 2, dh = (sh + 1) / 2, x, y, k;
+    int* rows = (int*)malloc(sizeof(int) * (size_t)dw * 5);
+    for (y = 0; y < dh; y++) {
+        for (k = 0; k < 5; k++) {
+            int sy = reflect101(2 * y + k - 2, sh);
+            const uint8_t* s = src + (size_t)sy * sstride;
+            int* r = rows + (size_t)k * dw;
+            for (x = 0; x < dw; x++) {
+                int x0 = reflect101(2 * x - 2, sw), x1 = reflect101(2 * x - 1, sw), x2 = 2 * x,
+                    x3 = reflect101(2 * x + 1, sw), x4 = reflect101(2 * x + 2, sw);
+                r[x] = s[x2] * 6 + (s[x1] + s[x3]) * 4 + s[x0] + s[x4];
+            }
+        }
+        for (x = 0; x < dw; x++) {
+            int v = rows[2 * dw + x] * 6 + (rows[dw + x] + rows[3 * dw + x]) * 4 + rows[x] + rows[4 * dw + x];
+            dst[(size_t)y * dstride + x] = (uint8_t)((v + 128) >> 8);
+        }
+    }
+    free(rows);
+}
+
+/* calcSharrDeriv: int16 interleaved (dx,dy); REFLECT_101 at the image edges. */
+void orc_scharr(const uint8_t* src, int w, int h, int sstride, int16_t* dst, int dstride) {
+    int x, y;
+    int* t0 = (int*)malloc(sizeof(int) * (size_t)(w + 2));
+    int* t1 = (int*)malloc(sizeof(int) * (size_t)(w + 2));
+    for (y = 0; y < h; y++) {
+        const uint8_t* r0 = src + (size_t)reflect101(y - 1, h) * sstride;
+        const uint8_t* r1 = src + (size_t)y * sstride;
+        const uint8_t* r2 = src + (size_t)reflect101(y + 1, h) * sstride;
+        for (x = 0; x < w; x++) {
+            t0[x + 1] = (r0[x] + r2[x]) * 3 + r1[x] * 10;
+            t1[x + 1] = r2[x] - r0[x];
+        }
+        /* border of the intermediate rows: REFLECT_101 in x */
+        t0[0] = t0[1 + reflect101(-1, w)]; t0[w + 1] = t0[1 + reflect101(w, w)];
+        t1[0] = t1[1 + reflect101(-1, w)]; t1[w + 1] = t1[1 + reflect101(w, w)];
+        int16_t* d = dst + (size_t)y * dstride;
+        for (x = 0; x < w; x++) {
+            d[2 * x]     = (int16_t)(t0[x + 2] - t0[x]);
+            d[2 * x + 1] = (int16_t)((t1[x + 2] + t1[x]) * 3 + t1[x + 1] * 10);
+        }
+    }
+    free(t0); free(t1);
+}
+
+static void make_level(orc_pyramid* p, int lvl, int w, int h) {
+    int pw = w + 2 * p->pad_x, ph = h + 2 * p->pad_y;
+    uint8_t* ibuf = (uint8_t*)malloc((size_t)pw * ph);
+    int16_t* dbuf = (int16_t*)calloc((size_t)pw * ph * 2, sizeof(int16_t));   /* deriv border = CONSTANT 0 */
+    p->owned[2 * lvl] = ibuf; p->owned[2 * lvl + 1] = dbuf;
+    p->w[lvl] = w; p->h[lvl] = h;
+    p->img_stride[lvl] = pw; p->deriv_stride[lvl] = pw * 2;
+    p->img[lvl] = ibuf + (size_t)p->pad_y * pw + p->pad_x;
+    p->deriv[lvl] = dbuf + ((size_t)p->pad_y * pw + p->pad_x) * 2;
+}
+
+static void fill_border_reflect101(orc_pyramid* p, int lvl) {
+    int w = p->w[lvl], h = p->h[lvl], st = p->img_stride[lvl], x, y;
+    uint8_t* im = p->img[lvl];
+    for (y = -p->pad_y; y < h + p->pad_y; y++) {
+        int sy = reflect101(y, h);
+        for (x = -p->pad_x; x < w + p->pad_x; x++) {
+            if (x >= 0 && x < w && y >= 0 && y < h) continue;
+            im[(ptrdiff_t)y * st + x] = im[(ptrdiff_t)sy * st + reflect101(x, w)];
+        }
+    }
+}
+
+void orc_build_pyramid(const uint8_t* img, int w, int h, int stride, int win_w, int win_h, int max_level, orc_pyramid* p) {
+    int lvl, y;
+    memset(p, 0, sizeof(*p));
+    p->pad_x = win_w; p->pad_y = win_h;
+    if (max_level > ORC_MAX_LEVELS - 1) max_level = ORC_MAX_LEVELS - 1;
+    int cw = w, ch = h;
+    for (lvl = 0; lvl <= max_level; lvl++) {
+        make_level(p, lvl, cw, ch);
+        if (lvl == 0) {
+            for (y = 0; y < h; y++) memcpy(p->img[0] + (size_t)y * p->img_stride[0], img + (size_t)y * stride, (size_t)w);
+        } else {
+            orc_pyr_down(p->img[lvl - 1], p->w[lvl - 1], p->h[lvl - 1], p->img_stride[lvl - 1], p->img[lvl], p->img_stride[lvl]);
+        }
+        fill_border_reflect101(p, lvl);
+        orc_scharr(p->img[lvl], cw, ch, p->img_stride[lvl], p->deriv[lvl], p->deriv_stride[lvl]);
+        p->nlevels = lvl + 1;
+        cw = (cw + 1) / 2; ch = (ch + 1) / 2;
+        if (cw <= win_w || ch <= win_h) break;     /* lkpyramid.cpp: stop when the NEXT level would not exceed the window */
+    }
+}
+
+void orc_pyramid_free(orc_pyramid* p) {
+    int i;
+    for (i = 0; i < 2 * ORC_MAX_LEVELS; i++) { free(p->owned[i]); p->owned[i] = NULL; }
+    p->nlevels = 0;
+}
+
+#define W_BITS 14
+#define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+
+static inline int cv_round_f(float v) { return (int)lrintf(v); }     /* round-half-even under the default mode */
+static inline int cv_floor_f(float v) { return (int)floorf(v); }
+
+/* One pyramid level of LKTrackerInvoker for all points. */
+static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int max_level, int n,
+                     const float* prev_pts, float* next_pts, uint8_t* status,
+                     int ww, int wh, int max_count, double epsilon, double min_eig_threshold) {
+    const float half_x = (ww - 1) * 0.5f, half_y = (wh - 1) * 0.5f;
+    const uint8_t* I = A->img[level]; const int stepI = A->img_stride[level];
+    const int16_t* dI = A->deriv[level]; const int dstep = A->deriv_stride[level];
+    const uint8_t* J = B->img[level]; const int stepJ = B->img_stride[level];
+    const int colsI = A->w[level], rowsI = A->h[level], colsJ = B->w[level], rowsJ = B->h[level];
+    const float FLT_SCALE = 1.f / (1 << 20);
+    int16_t* Iw = (int16_t*)malloc(sizeof(int16_t) * (size_t)ww * wh * 3);
+    int16_t* dIw = Iw + (size_t)ww * wh;
+    const float scale = (float)(1. / (1 << level));
+    int i, x, y, j;
+
+    for (i = 0; i < n; i++) {
+        float ppx = prev_pts[2 * i] * scale, ppy = prev_pts[2 * i + 1] * scale;
+        float npx, npy;
+        if (level == max_level) { npx = ppx; npy = ppy; }
+        else { npx = next_pts[2 * i] * 2.f; npy = next_pts[2 * i + 1] * 2.f; }
+        next_pts[2 * i] = npx; next_pts[2 * i + 1] = npy;
+
+        ppx -= half_x; ppy -= half_y;
+        int ipx = cv_floor_f(ppx), ipy = cv_floor_f(ppy);
+        if (ipx < -ww || ipx >= colsI || ipy < -wh || ipy >= rowsI) {
+            if (level == 0) status[i] = 0;
+            continue;
+        }
+        float a = ppx - ipx, b = ppy - ipy;
+        int iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
+        int iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
+        int iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        int64_t iA11 = 0, iA12 = 0, iA22 = 0;
+        for (y = 0; y < wh; y++) {
+            const uint8_t* src = I + (ptrdiff_t)(y + ipy) * stepI + ipx;
+            const int16_t* ds = dI + (ptrdiff_t)(y + ipy) * dstep + ipx * 2;
+            int16_t* Ip = Iw + (size_t)y * ww;
+            int16_t* dp = dIw + (size_t)y * ww * 2;
+            for (x = 0; x < ww; x++, ds += 2, dp += 2) {
+                int ival = DESCALE(src[x] * iw00 + src[x + 1] * iw01 + src[x + stepI] * iw10 + src[x + stepI + 1] * iw11, W_BITS - 5);
+                int ixval = DESCALE(ds[0] * iw00 + ds[2] * iw01 + ds[dstep] * iw10 + ds[dstep + 2] * iw11, W_BITS);
+                int iyval = DESCALE(ds[1] * iw00 + ds[3] * iw01 + ds[dstep + 1] * iw10 + ds[dstep + 3] * iw11, W_BITS);
+                Ip[x] = (int16_t)ival; dp[0] = (int16_t)ixval; dp[1] = (int16_t)iyval;
+                iA11 += (int64_t)(ixval * ixval); iA12 += (int64_t)(ixval * iyval); iA22 += (int64_t)(iyval * iyval);
+            }
+        }
+        /* |sum| < 2^53: int64 -> double is exact, double -> float rounds once (nearest-even) */
+        float A11 = (float)(double)iA11 * FLT_SCALE, A12 = (float)(double)iA12 * FLT_SCALE, A22 = (float)(double)iA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww * wh);
+        if ((double)minEig < min_eig_threshold || D < 1.1920928955078125e-07f /* FLT_EPSILON */) {
+            if (level == 0) status[i] = 0;
+            continue;
+        }
+        D = 1.f / D;
+        npx -= half_x; npy -= half_y;
+        float pdx = 0.f, pdy = 0.f;
+        for (j = 0; j < max_count; j++) {
+            int inx = cv_floor_f(npx), iny = cv_floor_f(npy);
+            if (inx < -ww || inx >= colsJ || iny < -wh || iny >= rowsJ) {
+                if (level == 0) status[i] = 0;
+                break;
+            }
+            a = npx - inx; b = npy - iny;
+            iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
+            iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
+            iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            int64_t ib1 = 0, ib2 = 0;
+            for (y = 0; y < wh; y++) {
+                const uint8_t* Jp = J + (ptrdiff_t)(y + iny) * stepJ + inx;
+                const int16_t* Ip = Iw + (size_t)y * ww;
+                const int16_t* dp = dIw + (size_t)y * ww * 2;
+                for (x = 0; x < ww; x++, dp += 2) {
+                    int diff = DESCALE(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stepJ] * iw10 + Jp[x + stepJ + 1] * iw11, W_BITS - 5) - Ip[x];
+                    ib1 += (int64_t)(diff * dp[0]); ib2 += (int64_t)(diff * dp[1]);
+                }
+            }
+            float b1 = (float)(double)ib1 * FLT_SCALE, b2 = (float)(double)ib2 * FLT_SCALE;
+            float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+            npx += dx; npy += dy;
+            next_pts[2 * i] = npx + half_x; next_pts[2 * i + 1] = npy + half_y;
+            if ((double)dx * dx + (double)dy * dy <= epsilon) break;
+            if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+                next_pts[2 * i] -= dx * 0.5f; next_pts[2 * i + 1] -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        /* flags=0 and err!=NULL (vo.cpp:182,203): the level-0 error block re-checks the final window origin */
+        if (status[i] && level == 0) {
+            float fx = next_pts[2 * i] - half_x, fy = next_pts[2 * i + 1] - half_y;
+            int ix = cv_floor_f(fx), iy = cv_floor_f(fy);
+            if (ix < -ww || ix >= colsJ || iy < -wh || iy >= rowsJ) status[i] = 0;
+        }
+    }
+    free(Iw);
+}
+
+void orc_lk_track(const orc_pyramid* prev, const orc_pyramid* next, int n, const float* prev_pts,
+                  float* next_pts, uint8_t* status, int win_w, int win_h, int max_level,
+                  int max_count, double epsilon, double min_eig_threshold) {
+    int level, i;
+    if (max_level > prev->nlevels - 1) max_level = prev->nlevels - 1;
+    if (max_level > next->nlevels - 1) max_level = next->nlevels - 1;
+    /* TermCriteria normalisation (lkpyramid.cpp) */
+    if (max_count < 0) max_count = 0;
+    if (max_count > 100) max_count = 100;
+    if (epsilon < 0.) epsilon = 0.;
+    if (epsilon > 10.) epsilon = 10.;
+    epsilon *= epsilon;
+    for (i = 0; i < n; i++) status[i] = 1;
+    for (level = max_level; level >= 0; level--)
+        lk_level(prev, next, level, max_level, n, prev_pts, next_pts, status, win_w, win_h, max_count, epsilon, min_eig_threshold);
+}
+
+/* vo.cpp:169-240 without the compaction (the mask is returned) */
+void orc_circular_match(const orc_pyramid* l0, const orc_pyramid* r0, const orc_pyramid* l1, const orc_pyramid* r1,
+                        int n, const float* pl0, float* pl1, float* pr1, float* pr0, float* pl0_circle,
+                        uint8_t* ok, const orc_config* cfg) {
+    uint8_t* st = (uint8_t*)malloc((size_t)n * 4 + 4);
+    int i;
+    orc_lk_track(l0, l1, n, pl0, pl1, st, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold);          /* :203 */
+    orc_lk_track(l1, r1, n, pl1, pr1, st + n, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold);      /* :206 */
+    orc_lk_track(r1, r0, n, pr1, pr0, st + 2 * n, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold);  /* :209 */
+    orc_lk_track(r0, l0, n, pr0, pl0_circle, st + 3 * n, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold); /* :213 */
+    orc_find_close_points(n, pl0, pl0_circle, (float)cfg->circular_matching_success_threshold, ok);   /* :217-219 (float32 threshold parameter) */
+    for (i = 0; i < n; i++) ok[i] = (uint8_t)(st[i] && st[n + i] && st[2 * n + i] && st[3 * n + i] && ok[i]);  /* :227-230 */
+    free(st);
+}
