@@ -1,0 +1,617 @@
+// svo_api.hip — host side of libsvo_hip.so: context, frame pipeline, C-ABI (include/svo.h).
+// The per-frame orchestration of VisualOdometry::stereo_callback (reference src/vo.cpp:41-137) is
+// expressed as a fixed sequence of kernel launches on one HIP stream; every data-dependent decision
+// (second FAST pass, too-few-tracks gate, RANSAC failure, motion gate, stale-pyramid quirk) is taken
+// on the device from SeqState, so a frame needs no host round trip until its pose is read back.
+#include "svo_internal.hpp"
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+extern "C" const char* svo_last_error(void) { return g_err.c_str(); }
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            char _b[512];                                                                         \
+            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            g_err = _b;                                                                           \
+            return SVO_ERR_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+static int fail_arg(const char* msg) { g_err = msg; return SVO_ERR_ARG; }
+
+extern "C" int svo_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void svo_config_default(svo_config* c) {
+    c->bucket_start_row = 4; c->buckets_along_height = 92; c->buckets_along_width = 160;
+    c->features_per_bucket = 1; c->features_threshold = 15; c->pre_matching_feature_threshold = 100;
+    c->age_threshold = 20; c->fast_threshold = 20; c->ransac_reprojection_error = 8.f;
+    c->ransac_iterations = 100; c->optical_flow_min_eig_threshold = 0.001;
+    c->circular_matching_success_threshold = .15; c->max_translation_norm = .1; c->max_rotation_norm = .5;
+    c->win_w = 10; c->win_h = 10; c->max_level = 3; c->lk_max_count = 30; c->lk_epsilon = 0.0001;
+    c->ransac_confidence = 0.98f; c->max_features = 0;
+}
+
+// cv::buildOpticalFlowPyramid's level rule: level 0 always, stop as soon as
+// the NEXT level would have width <= win or height <= win.
+static void make_geometry(Geometry& g, int W, int H, int win, int max_level) {
+    memset(&g, 0, sizeof(g));
+    g.W = W; g.H = H;
+    if (max_level > SVO_MAX_LEVELS - 1) max_level = SVO_MAX_LEVELS - 1;
+    int w = W, h = H, off = 0;
+    for (int l = 0; l <= max_level; l++) {
+        g.lv[l].w = w; g.lv[l].h = h; g.lv[l].off = off;
+        off += (w * h + 15) & ~15;
+        g.nlevels = l + 1;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+        if (w <= win || h <= win) break;
+    }
+    g.pyr_bytes = off;
+}
+
+struct svo_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuffers d = {};
+    std::vector<void*> allocs;
+    // host side of the results ring
+    FrameResult* h_results = nullptr;            // pinned [SVO_RING][B]
+    const uint8_t** h_ptrs = nullptr;            // pinned [SVO_RING][2][B]
+    hipEvent_t ev_done[SVO_RING] = {}, ev_f0[SVO_RING] = {}, ev_lk0[SVO_RING] = {}, ev_lk1[SVO_RING] = {};
+    int head = 0, tail = 0, inflight = 0;        // ring indices: head = next to enqueue, tail = oldest outstanding
+    int last_slot = -1;
+    uint8_t* staging = nullptr;                  // device [2][B][W*H] for host-image calls
+    bool projection_set = false;
+    int lk_grid = 0;
+};
+
+template <typename T>
+static int dev_alloc(svo_context* c, T** p, size_t count) {
+    void* q = nullptr;
+    HIPCHK(hipMalloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 16));
+    HIPCHK(hipMemsetAsync(q, 0, count * sizeof(T) > 0 ? count * sizeof(T) : 16, c->stream));
+    c->allocs.push_back(q);
+    *p = (T*)q;
+    return SVO_OK;
+}
+
+static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width, int height, int cap_override, svo_context** out) {
+    if (!out) return fail_arg("out is null");
+    *out = nullptr;
+    svo_config cfg;
+    if (cfg_in) cfg = *cfg_in; else svo_config_default(&cfg);
+    if (n_seq < 1 || width < 16 || height < 16) return fail_arg("n_seq >= 1 and width/height >= 16 required");
+    if (cfg.win_w != cfg.win_h || !lk_window_supported(cfg.win_w)) return fail_arg("unsupported LK window (square 7, 10, 15, 21 or 31)");
+    if (width <= cfg.win_w || height <= cfg.win_h) return fail_arg("image must be larger than the LK window");
+    if (cfg.features_per_bucket != 1) return fail_arg("the frame pipeline supports features_per_bucket == 1 (use svo_bucket_filter for other capacities)");
+    if (cfg.buckets_along_height < 1 || cfg.buckets_along_width < 1 || cfg.ransac_iterations < 1) return fail_arg("bad bucket grid / ransac_iterations");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail_arg("no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    svo_context* c = new svo_context();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    DevBuffers& d = c->d;
+    d.B = n_seq; d.cfg = cfg; d.K = cfg.ransac_iterations;
+    d.NB = cfg.buckets_along_height * cfg.buckets_along_width;
+    d.bucket_h = (height + cfg.buckets_along_height - 1) / cfg.buckets_along_height;     // feature_set.cpp:91-93,103-104
+    d.bucket_w = (width + cfg.buckets_along_width - 1) / cfg.buckets_along_width;
+    int rows = cfg.buckets_along_height - cfg.bucket_start_row; if (rows < 0) rows = 0;
+    d.CAP = rows * cfg.buckets_along_width;
+    if (d.CAP < 64) d.CAP = 64;
+    if (cap_override > d.CAP) d.CAP = cap_override;
+    c->lk_grid = (cfg.max_features > 0 && cfg.max_features < d.CAP) ? cfg.max_features : d.CAP;
+    make_geometry(d.geom, width, height, cfg.win_w, cfg.max_level);
+    const size_t B = n_seq, CAP = d.CAP;
+    int rc;
+#define ALLOC(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != SVO_OK) return rc;
+    ALLOC(d.st, B);
+    ALLOC(d.pyr, B * 6 * (size_t)d.geom.pyr_bytes);
+    for (int k = 0; k < 2; k++) { ALLOC(d.feat_xy[k], B * CAP); ALLOC(d.feat_age[k], B * CAP); ALLOC(d.feat_str[k], B * CAP); }
+    ALLOC(d.bucket_keys, B * (size_t)d.NB);
+    ALLOC(d.pl0, B * CAP); ALLOC(d.pl1, B * CAP); ALLOC(d.pr1, B * CAP); ALLOC(d.pr0, B * CAP); ALLOC(d.plc, B * CAP);
+    ALLOC(d.okmask, B * CAP);
+    ALLOC(d.tl0, B * CAP); ALLOC(d.tr0, B * CAP); ALLOC(d.tl1, B * CAP); ALLOC(d.tr1, B * CAP);
+    ALLOC(d.world, B * CAP * 3); ALLOC(d.inlier, B * CAP); ALLOC(d.inl_idx, B * CAP);
+    ALLOC(d.subsets, B * (size_t)d.K * 5); ALLOC(d.hyp, B * (size_t)d.K * 12); ALLOC(d.hyp_good, B * (size_t)d.K);
+    ALLOC(d.results, (size_t)SVO_RING * B);
+    ALLOC(d.img_ptrs, (size_t)SVO_RING * 2 * B);
+#undef ALLOC
+    HIPCHK(hipHostMalloc((void**)&c->h_results, sizeof(FrameResult) * SVO_RING * B));
+    HIPCHK(hipHostMalloc((void**)&c->h_ptrs, sizeof(uint8_t*) * SVO_RING * 2 * B));
+    for (int i = 0; i < SVO_RING; i++) {
+        HIPCHK(hipEventCreate(&c->ev_done[i])); HIPCHK(hipEventCreate(&c->ev_f0[i]));
+        HIPCHK(hipEventCreate(&c->ev_lk0[i])); HIPCHK(hipEventCreate(&c->ev_lk1[i]));
+    }
+    // initial state: rotation = I, translation = 0, last_transform = I (vo.h:266-268); no slots in use
+    std::vector<SeqState> hs(B);
+    memset(hs.data(), 0, sizeof(SeqState) * B);
+    for (size_t i = 0; i < B; i++) {
+        hs[i].slot_img_t0 = -1; hs[i].slot_pyr_t0 = -1;
+        for (int k = 0; k < 9; k++) hs[i].R[k] = (k % 4 == 0);
+        for (int k = 0; k < 16; k++) hs[i].last_T[k] = (k % 5 == 0);
+    }
+    HIPCHK(hipMemcpyAsync(d.st, hs.data(), sizeof(SeqState) * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = c;
+    return SVO_OK;
+}
+
+extern "C" int svo_create(const svo_config* cfg, int device, int n_seq, int width, int height, svo_context** out) {
+    return ctx_create(cfg, device, n_seq, width, height, 0, out);
+}
+
+extern "C" void svo_destroy(svo_context* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) hipFree(p);
+    if (c->staging) hipFree(c->staging);
+    if (c->h_results) hipHostFree(c->h_results);
+    if (c->h_ptrs) hipHostFree((void*)c->h_ptrs);
+    for (int i = 0; i < SVO_RING; i++) {
+        if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]);
+        if (c->ev_f0[i]) hipEventDestroy(c->ev_f0[i]);
+        if (c->ev_lk0[i]) hipEventDestroy(c->ev_lk0[i]);
+        if (c->ev_lk1[i]) hipEventDestroy(c->ev_lk1[i]);
+    }
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void* svo_get_stream(svo_context* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int svo_set_projection(svo_context* c, int seq, const float Pl[12], const float Pr[12]) {
+    if (!c || !Pl || !Pr) return fail_arg("null argument");
+    if (seq < -1 || seq >= c->d.B) return fail_arg("seq out of range");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float K[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) K[3 * i + j] = Pl[4 * i + j];      // vo.cpp:16-25
+    for (int s = (seq < 0 ? 0 : seq); s < (seq < 0 ? c->d.B : seq + 1); s++) {
+        SeqState* ds = c->d.st + s;
+        HIPCHK(hipMemcpy(&ds->Pl, Pl, sizeof(float) * 12, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(&ds->Pr, Pr, sizeof(float) * 12, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(&ds->K, K, sizeof(float) * 9, hipMemcpyHostToDevice));
+    }
+    c->projection_set = true;
+    return SVO_OK;
+}
+
+// Enqueue one frame for all sequences.  ptrs: host array [2][B] of DEVICE image pointers.
+static int enqueue_frame(svo_context* c, const uint8_t* const* left_dev, const uint8_t* const* right_dev, int stride) {
+    if (c->inflight >= SVO_RING) { g_err = "too many frames in flight (collect first)"; return SVO_ERR_STATE; }
+    DevBuffers& d = c->d;
+    const int slot = c->head, B = d.B;
+    const uint8_t** hp = c->h_ptrs + (size_t)slot * 2 * B;
+    for (int i = 0; i < B; i++) { hp[i] = left_dev[i]; hp[B + i] = right_dev[i]; }
+    const uint8_t** dp = d.img_ptrs + (size_t)slot * 2 * B;
+    hipStream_t s = c->stream;
+    HIPCHK(hipEventRecord(c->ev_f0[slot], s));
+    HIPCHK(hipMemcpyAsync((void*)dp, (const void*)hp, sizeof(uint8_t*) * 2 * B, hipMemcpyHostToDevice, s));
+    launch_frame_begin(d, s);
+    launch_ingest(d, dp, stride, s);
+    launch_pyramid(d, s);
+    launch_detect(d, 0, -1, s);
+    launch_detect(d, 1, -1, s);
+    HIPCHK(hipEventRecord(c->ev_lk0[slot], s));
+    launch_lk_chain(d, c->lk_grid, s);
+    HIPCHK(hipEventRecord(c->ev_lk1[slot], s));
+    launch_compact(d, s);
+    launch_triangulate(d, s);
+    launch_pnp(d, s);
+    launch_frame_end(d, slot, s);
+    HIPCHK(hipMemcpyAsync(c->h_results + (size_t)slot * B, d.results + (size_t)slot * B, sizeof(FrameResult) * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(c->ev_done[slot], s));
+    HIPCHK(hipGetLastError());
+    c->head = (c->head + 1) % SVO_RING; c->inflight++;
+    return SVO_OK;
+}
+
+static int collect_frame(svo_context* c, double* T_out, int* ok_out, svo_frame_stats* stats) {
+    if (c->inflight <= 0) { g_err = "nothing to collect"; return SVO_ERR_STATE; }
+    const int slot = c->tail, B = c->d.B;
+    HIPCHK(hipEventSynchronize(c->ev_done[slot]));
+    const FrameResult* r = c->h_results + (size_t)slot * B;
+    for (int i = 0; i < B; i++) {
+        if (T_out) memcpy(T_out + 16 * i, r[i].T, sizeof(double) * 16);
+        if (ok_out) ok_out[i] = r[i].ok;
+        if (stats) stats[i] = r[i].stats;
+    }
+    c->last_slot = slot;
+    c->tail = (c->tail + 1) % SVO_RING; c->inflight--;
+    return SVO_OK;
+}
+
+extern "C" int svo_submit_batch(svo_context* c, const uint8_t* const* left_dev, const uint8_t* const* right_dev, int stride) {
+    if (!c || !left_dev || !right_dev) return fail_arg("null argument");
+    if (!c->projection_set) { g_err = "svo_set_projection must be called first"; return SVO_ERR_STATE; }
+    if (stride < c->d.geom.W) return fail_arg("stride < width");
+    HIPCHK(hipSetDevice(c->device));
+    return enqueue_frame(c, left_dev, right_dev, stride);
+}
+
+extern "C" int svo_collect(svo_context* c, double* T_out, int* ok_out, svo_frame_stats* stats) {
+    if (!c) return fail_arg("null context");
+    HIPCHK(hipSetDevice(c->device));
+    return collect_frame(c, T_out, ok_out, stats);
+}
+
+extern "C" int svo_process_batch(svo_context* c, const uint8_t* const* left, const uint8_t* const* right, int stride,
+                                 int images_on_device, double* T_out, int* ok_out, svo_frame_stats* stats) {
+    if (!c || !left || !right) return fail_arg("null argument");
+    if (!c->projection_set) { g_err = "svo_set_projection must be called first"; return SVO_ERR_STATE; }
+    if (stride < c->d.geom.W) return fail_arg("stride < width");
+    if (c->inflight != 0) { g_err = "svo_process_batch with frames in flight"; return SVO_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    const int B = c->d.B, W = c->d.geom.W, H = c->d.geom.H;
+    int rc;
+    if (images_on_device) {
+        rc = enqueue_frame(c, left, right, stride);
+    } else {
+        // the caller's buffers are only borrowed for the duration of the call: copy to the device first (SURVEY.md §8b "Ownership")
+        const size_t img = (size_t)W * H;
+        if (!c->staging) HIPCHK(hipMalloc((void**)&c->staging, img * 2 * B));
+        std::vector<const uint8_t*> lp(B), rp(B);
+        for (int i = 0; i < B; i++) {
+            if (!left[i] || !right[i]) return fail_arg("null image pointer");
+            uint8_t* dl = c->staging + img * i; uint8_t* dr = c->staging + img * (B + i);
+            HIPCHK(hipMemcpy2DAsync(dl, W, left[i], stride, W, H, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpy2DAsync(dr, W, right[i], stride, W, H, hipMemcpyHostToDevice, c->stream));
+            lp[i] = dl; rp[i] = dr;
+        }
+        rc = enqueue_frame(c, lp.data(), rp.data(), W);
+    }
+    if (rc != SVO_OK) return rc;
+    return collect_frame(c, T_out, ok_out, stats);
+}
+
+extern "C" int svo_process(svo_context* c, const uint8_t* left, const uint8_t* right, int stride, double T_out[16], svo_frame_stats* stats) {
+    if (!c) return fail_arg("null context");
+    if (c->d.B != 1) return fail_arg("svo_process needs a context created with n_seq == 1");
+    int ok = 0;
+    const uint8_t* l[1] = {left}; const uint8_t* r[1] = {right};
+    int rc = svo_process_batch(c, l, r, stride, 0, T_out, &ok, stats);
+    return rc != SVO_OK ? rc : ok;
+}
+
+extern "C" int svo_get_last_timing(svo_context* c, float* lk_ms, float* frame_ms) {
+    if (!c || c->last_slot < 0) return fail_arg("no frame collected yet");
+    HIPCHK(hipSetDevice(c->device));
+    const int s = c->last_slot;
+    if (lk_ms) HIPCHK(hipEventElapsedTime(lk_ms, c->ev_lk0[s], c->ev_lk1[s]));
+    if (frame_ms) HIPCHK(hipEventElapsedTime(frame_ms, c->ev_f0[s], c->ev_done[s]));
+    return SVO_OK;
+}
+
+static int read_state(svo_context* c, int seq, SeqState* hs) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(hs, c->d.st + seq, sizeof(SeqState), hipMemcpyDeviceToHost));
+    return SVO_OK;
+}
+
+extern "C" int svo_get_features(svo_context* c, int seq, int cap, float* xy, int* ages, int* strengths) {
+    if (!c || seq < 0 || seq >= c->d.B) return fail_arg("bad context / seq");
+    SeqState hs; int rc = read_state(c, seq, &hs); if (rc != SVO_OK) return rc;
+    int n = hs.n_feat < cap ? hs.n_feat : cap;
+    const size_t o = (size_t)seq * c->d.CAP;
+    if (n > 0) {
+        if (xy) HIPCHK(hipMemcpy(xy, c->d.feat_xy[hs.feat_buf] + o, sizeof(float2) * n, hipMemcpyDeviceToHost));
+        if (ages) HIPCHK(hipMemcpy(ages, c->d.feat_age[hs.feat_buf] + o, sizeof(int) * n, hipMemcpyDeviceToHost));
+        if (strengths) HIPCHK(hipMemcpy(strengths, c->d.feat_str[hs.feat_buf] + o, sizeof(int) * n, hipMemcpyDeviceToHost));
+    }
+    return hs.n_feat;
+}
+
+extern "C" int svo_get_last_tracks(svo_context* c, int seq, int cap, float* pl0, float* pr0, float* pl1, float* pr1, float* world, uint8_t* inlier) {
+    if (!c || seq < 0 || seq >= c->d.B) return fail_arg("bad context / seq");
+    SeqState hs; int rc = read_state(c, seq, &hs); if (rc != SVO_OK) return rc;
+    int n = hs.n_tracks < cap ? hs.n_tracks : cap;
+    const size_t o = (size_t)seq * c->d.CAP;
+    if (n > 0) {
+        if (pl0) HIPCHK(hipMemcpy(pl0, c->d.tl0 + o, sizeof(float2) * n, hipMemcpyDeviceToHost));
+        if (pr0) HIPCHK(hipMemcpy(pr0, c->d.tr0 + o, sizeof(float2) * n, hipMemcpyDeviceToHost));
+        if (pl1) HIPCHK(hipMemcpy(pl1, c->d.tl1 + o, sizeof(float2) * n, hipMemcpyDeviceToHost));
+        if (pr1) HIPCHK(hipMemcpy(pr1, c->d.tr1 + o, sizeof(float2) * n, hipMemcpyDeviceToHost));
+        if (world) HIPCHK(hipMemcpy(world, c->d.world + 3 * o, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
+        if (inlier) HIPCHK(hipMemcpy(inlier, c->d.inlier + o, (size_t)n, hipMemcpyDeviceToHost));
+    }
+    return hs.n_tracks;
+}
+
+// ================================================================================================
+// Stage-level entry points
+// ================================================================================================
+struct DevTmp {                                   // RAII-ish scratch allocations for the stage calls
+    std::vector<void*> p;
+    ~DevTmp() { for (void* q : p) hipFree(q); }
+    template <typename T> hipError_t get(T** out, size_t count) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
+        if (e == hipSuccess) { p.push_back(q); *out = (T*)q; }
+        return e;
+    }
+};
+
+static int use_device(int device) {
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail_arg("no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    return SVO_OK;
+}
+
+struct CtxGuard { svo_context* c = nullptr; ~CtxGuard() { svo_destroy(c); } };
+
+static int upload_image(svo_context* c, int slot, int cam, const uint8_t* img, int stride) {
+    uint8_t* dst = c->d.pyr + pyr_index(c->d, 0, slot, cam);
+    HIPCHK(hipMemcpy2DAsync(dst, c->d.geom.W, img, stride, c->d.geom.W, c->d.geom.H, hipMemcpyHostToDevice, c->stream));
+    return SVO_OK;
+}
+static int set_state(svo_context* c, const SeqState& hs) {
+    HIPCHK(hipMemcpyAsync(c->d.st, &hs, sizeof(SeqState), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));      // hs is a stack object
+    return SVO_OK;
+}
+static int build_pyramid_in_slot(svo_context* c, SeqState& hs, int slot) {
+    hs.slot_t1 = slot;
+    int rc = set_state(c, hs); if (rc != SVO_OK) return rc;
+    launch_pyramid(c->d, c->stream);
+    return SVO_OK;
+}
+
+extern "C" int svo_fast_score_map(int device, const uint8_t* img, int w, int h, int stride, int threshold, uint8_t* score) {
+    if (!img || !score || w < 7 || h < 7 || stride < w) return fail_arg("bad image arguments");
+    int rc = use_device(device); if (rc != SVO_OK) return rc;
+    DevTmp t; uint8_t *dimg, *dsc;
+    HIPCHK(t.get(&dimg, (size_t)w * h)); HIPCHK(t.get(&dsc, (size_t)w * h));
+    HIPCHK(hipMemcpy2D(dimg, w, img, stride, w, h, hipMemcpyHostToDevice));
+    launch_fast_score_map(dimg, w, h, threshold, dsc, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(score, dsc, (size_t)w * h, hipMemcpyDeviceToHost));
+    return SVO_OK;
+}
+
+extern "C" int svo_fast_detect(int device, const uint8_t* img, int w, int h, int stride, int threshold,
+                               int cap, float* xy, float* resp, int* n_out) {
+    if (!img || !n_out || w < 7 || h < 7 || stride < w || cap < 0) return fail_arg("bad arguments");
+    int rc = use_device(device); if (rc != SVO_OK) return rc;
+    DevTmp t; uint8_t *dimg, *dsc; int *rows, *dn; float2* dxy; float* dresp;
+    HIPCHK(t.get(&dimg, (size_t)w * h)); HIPCHK(t.get(&dsc, (size_t)w * h)); HIPCHK(t.get(&rows, (size_t)h));
+    HIPCHK(t.get(&dn, 1)); HIPCHK(t.get(&dxy, (size_t)cap)); HIPCHK(t.get(&dresp, (size_t)cap));
+    HIPCHK(hipMemcpy2D(dimg, w, img, stride, w, h, hipMemcpyHostToDevice));
+    launch_fast_score_map(dimg, w, h, threshold, dsc, 0);
+    launch_score_compact(dsc, w, h, cap, rows, dxy, dresp, dn, 0);
+    HIPCHK(hipGetLastError());
+    int n = 0;
+    HIPCHK(hipMemcpy(&n, dn, sizeof(int), hipMemcpyDeviceToHost));
+    int m = n < cap ? n : cap;
+    if (m > 0 && xy) HIPCHK(hipMemcpy(xy, dxy, sizeof(float2) * m, hipMemcpyDeviceToHost));
+    if (m > 0 && resp) HIPCHK(hipMemcpy(resp, dresp, sizeof(float) * m, hipMemcpyDeviceToHost));
+    *n_out = n;
+    return SVO_OK;
+}
+
+extern "C" int svo_bucket_filter(int device, int img_w, int img_h, int* n_io, float* xy, int* ages, int* strengths,
+                                 int bah, int baw, int start_row, int per_bucket, int age_thr, int fast_thr) {
+    if (!n_io || *n_io < 0 || bah < 1 || baw < 1 || per_bucket < 0 || img_w < 1 || img_h < 1) return fail_arg("bad arguments");
+    int n = *n_io;
+    if (n > 0 && (!xy || !ages || !strengths)) return fail_arg("null arrays");
+    int rc = use_device(device); if (rc != SVO_OK) return rc;
+    if (n == 0 || per_bucket == 0) { *n_io = 0; return SVO_OK; }
+    const int nb = bah * baw;
+    DevTmp t; float2 *dxy, *sxy, *oxy; int *dag, *dst_, *sag, *sst, *sn, *oag, *ost, *dn;
+    const size_t outcap = (size_t)n;
+    HIPCHK(t.get(&dxy, (size_t)n)); HIPCHK(t.get(&dag, (size_t)n)); HIPCHK(t.get(&dst_, (size_t)n));
+    HIPCHK(t.get(&sxy, (size_t)nb * per_bucket)); HIPCHK(t.get(&sag, (size_t)nb * per_bucket)); HIPCHK(t.get(&sst, (size_t)nb * per_bucket));
+    HIPCHK(t.get(&sn, (size_t)nb)); HIPCHK(t.get(&oxy, outcap)); HIPCHK(t.get(&oag, outcap)); HIPCHK(t.get(&ost, outcap)); HIPCHK(t.get(&dn, 1));
+    HIPCHK(hipMemcpy(dxy, xy, sizeof(float2) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dag, ages, sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dst_, strengths, sizeof(int) * n, hipMemcpyHostToDevice));
+    launch_bucket_general(img_w, img_h, n, dxy, dag, dst_, bah, baw, start_row, per_bucket, age_thr, fast_thr, sxy, sag, sst, sn, oxy, oag, ost, dn, 0);
+    HIPCHK(hipGetLastError());
+    int m = 0;
+    HIPCHK(hipMemcpy(&m, dn, sizeof(int), hipMemcpyDeviceToHost));
+    if (m > 0) {
+        HIPCHK(hipMemcpy(xy, oxy, sizeof(float2) * m, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ages, oag, sizeof(int) * m, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(strengths, ost, sizeof(int) * m, hipMemcpyDeviceToHost));
+    }
+    *n_io = m;
+    return SVO_OK;
+}
+
+extern "C" int svo_append_features_from_image(int device, const svo_config* cfg_in, const uint8_t* img, int w, int h, int stride,
+                                              int fast_threshold, int cap, int* n_io, float* xy, int* ages, int* strengths) {
+    if (!img || !n_io || *n_io < 0 || stride < w || cap < *n_io) return fail_arg("bad arguments");
+    svo_config cfg; if (cfg_in) cfg = *cfg_in; else svo_config_default(&cfg);
+    CtxGuard g; int rc = ctx_create(&cfg, device, 1, w, h, *n_io, &g.c); if (rc != SVO_OK) return rc;
+    svo_context* c = g.c;
+    const int n = *n_io;
+    if (n > 0) {
+        if (!xy || !ages || !strengths) return fail_arg("null arrays");
+        HIPCHK(hipMemcpyAsync(c->d.feat_xy[0], xy, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d.feat_age[0], ages, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d.feat_str[0], strengths, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    }
+    rc = upload_image(c, 0, 0, img, stride); if (rc != SVO_OK) return rc;
+    SeqState hs; memset(&hs, 0, sizeof(hs));
+    hs.frame_id = 1; hs.active = 1; hs.slot_img_t0 = 0; hs.slot_pyr_t0 = 0; hs.slot_t1 = 1; hs.n_feat = n; hs.feat_buf = 0;
+    rc = set_state(c, hs); if (rc != SVO_OK) return rc;
+    launch_detect(c->d, 0, fast_threshold, c->stream);
+    HIPCHK(hipGetLastError());
+    int m = svo_get_features(c, 0, cap, xy, ages, strengths);
+    if (m < 0) return m;
+    *n_io = m;
+    return SVO_OK;
+}
+
+extern "C" int svo_build_pyramid(int device, const uint8_t* img, int w, int h, int stride, int win, int max_level,
+                                 uint8_t* levels_out, int64_t levels_cap, int* n_levels_out) {
+    if (!img || !levels_out || !n_levels_out || stride < w) return fail_arg("bad arguments");
+    svo_config cfg; svo_config_default(&cfg);
+    cfg.win_w = cfg.win_h = lk_window_supported(win) ? win : 10; cfg.max_level = max_level;
+    CtxGuard g; int rc = ctx_create(&cfg, device, 1, w, h, 0, &g.c); if (rc != SVO_OK) return rc;
+    svo_context* c = g.c;
+    make_geometry(c->d.geom, w, h, win, max_level);       // honour the caller's window for the level-stop rule
+    // (pyramid buffers were sized with a window >= 7, which never yields fewer bytes than a larger window)
+    Geometry chk; make_geometry(chk, w, h, cfg.win_w, max_level);
+    if (c->d.geom.pyr_bytes > chk.pyr_bytes) return fail_arg("window too small for this entry point");
+    rc = upload_image(c, 0, 0, img, stride); if (rc != SVO_OK) return rc;
+    SeqState hs; memset(&hs, 0, sizeof(hs));
+    rc = build_pyramid_in_slot(c, hs, 0); if (rc != SVO_OK) return rc;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int64_t off = 0;
+    for (int l = 0; l < c->d.geom.nlevels; l++) {
+        const LevelInfo& L = c->d.geom.lv[l];
+        int64_t sz = (int64_t)L.w * L.h;
+        if (off + sz > levels_cap) return fail_arg("levels_out too small");
+        HIPCHK(hipMemcpy(levels_out + off, c->d.pyr + pyr_index(c->d, 0, 0, 0) + L.off, (size_t)sz, hipMemcpyDeviceToHost));
+        off += sz;
+    }
+    *n_levels_out = c->d.geom.nlevels;
+    return SVO_OK;
+}
+
+extern "C" int svo_lk_track(int device, const uint8_t* prev_img, const uint8_t* next_img, int w, int h, int stride,
+                            int n, const float* prev_pts, float* next_pts, uint8_t* status,
+                            int win, int max_level, int max_count, double epsilon, double min_eig_threshold) {
+    if (!prev_img || !next_img || n < 0 || stride < w) return fail_arg("bad arguments");
+    if (n > 0 && (!prev_pts || !next_pts || !status)) return fail_arg("null arrays");
+    svo_config cfg; svo_config_default(&cfg);
+    cfg.win_w = cfg.win_h = win; cfg.max_level = max_level; cfg.lk_max_count = max_count; cfg.lk_epsilon = epsilon;
+    cfg.optical_flow_min_eig_threshold = min_eig_threshold;
+    CtxGuard g; int rc = ctx_create(&cfg, device, 1, w, h, n, &g.c); if (rc != SVO_OK) return rc;
+    svo_context* c = g.c;
+    if (n == 0) return SVO_OK;
+    if ((rc = upload_image(c, 0, 0, prev_img, stride)) != SVO_OK) return rc;
+    if ((rc = upload_image(c, 1, 0, next_img, stride)) != SVO_OK) return rc;
+    SeqState hs; memset(&hs, 0, sizeof(hs));
+    if ((rc = build_pyramid_in_slot(c, hs, 0)) != SVO_OK) return rc;
+    if ((rc = build_pyramid_in_slot(c, hs, 1)) != SVO_OK) return rc;
+    HIPCHK(hipMemcpyAsync(c->d.pl0, prev_pts, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    launch_lk_single(c->d, 0, 0, 1, 0, n, c->d.pl0, c->d.pl1, c->d.okmask, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(next_pts, c->d.pl1, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(status, c->d.okmask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SVO_OK;
+}
+
+extern "C" int svo_circular_match(int device, const svo_config* cfg_in, const uint8_t* l0, const uint8_t* r0,
+                                  const uint8_t* l1, const uint8_t* r1, int w, int h, int stride,
+                                  int n, const float* pl0, float* pl1, float* pr1, float* pr0, float* pl0_circle, uint8_t* ok) {
+    if (!l0 || !r0 || !l1 || !r1 || n < 0 || stride < w) return fail_arg("bad arguments");
+    if (n > 0 && (!pl0 || !pl1 || !pr1 || !pr0 || !pl0_circle || !ok)) return fail_arg("null arrays");
+    svo_config cfg; if (cfg_in) cfg = *cfg_in; else svo_config_default(&cfg);
+    cfg.max_features = 0;
+    CtxGuard g; int rc = ctx_create(&cfg, device, 1, w, h, n, &g.c); if (rc != SVO_OK) return rc;
+    svo_context* c = g.c;
+    if (n == 0) return SVO_OK;                                                    // vo.cpp:179-181
+    if ((rc = upload_image(c, 0, 0, l0, stride)) != SVO_OK) return rc;
+    if ((rc = upload_image(c, 0, 1, r0, stride)) != SVO_OK) return rc;
+    if ((rc = upload_image(c, 1, 0, l1, stride)) != SVO_OK) return rc;
+    if ((rc = upload_image(c, 1, 1, r1, stride)) != SVO_OK) return rc;
+    SeqState hs; memset(&hs, 0, sizeof(hs));
+    if ((rc = build_pyramid_in_slot(c, hs, 0)) != SVO_OK) return rc;
+    hs.frame_id = 1; hs.active = 1; hs.slot_img_t0 = 0; hs.slot_pyr_t0 = 0; hs.n_feat = n; hs.feat_buf = 0;
+    if ((rc = build_pyramid_in_slot(c, hs, 1)) != SVO_OK) return rc;             // leaves slot_t1 = 1
+    HIPCHK(hipMemcpyAsync(c->d.feat_xy[0], pl0, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    launch_lk_chain(c->d, n, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(pl1, c->d.pl1, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(pr1, c->d.pr1, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(pr0, c->d.pr0, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(pl0_circle, c->d.plc, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(ok, c->d.okmask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) ok[i] &= 1;                                       // bit0 = status0..3 && loop closure (vo.cpp:227-230)
+    return SVO_OK;
+}
+
+extern "C" int svo_find_close_points(int device, int n, const float* p1, const float* p2, float threshold, uint8_t* ok) {
+    if (n < 0 || (n > 0 && (!p1 || !p2 || !ok))) return fail_arg("bad arguments");
+    int rc = use_device(device); if (rc != SVO_OK) return rc;
+    if (n == 0) return SVO_OK;
+    DevTmp t; float2 *a, *b; uint8_t* o;
+    HIPCHK(t.get(&a, (size_t)n)); HIPCHK(t.get(&b, (size_t)n)); HIPCHK(t.get(&o, (size_t)n));
+    HIPCHK(hipMemcpy(a, p1, sizeof(float2) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b, p2, sizeof(float2) * n, hipMemcpyHostToDevice));
+    launch_find_close(n, a, b, threshold, o, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(ok, o, (size_t)n, hipMemcpyDeviceToHost));
+    return SVO_OK;
+}
+
+extern "C" int svo_triangulate(int device, const float Pl[12], const float Pr[12], int n, const float* pts_l, const float* pts_r, float* xyz) {
+    if (!Pl || !Pr || n < 0 || (n > 0 && (!pts_l || !pts_r || !xyz))) return fail_arg("bad arguments");
+    svo_config cfg; svo_config_default(&cfg);
+    CtxGuard g; int rc = ctx_create(&cfg, device, 1, 64, 64, n, &g.c); if (rc != SVO_OK) return rc;
+    svo_context* c = g.c;
+    if (n == 0) return SVO_OK;
+    SeqState hs; memset(&hs, 0, sizeof(hs));
+    hs.active = 1; hs.fail_reason = 0; hs.n_tracks = n;
+    memcpy(hs.Pl, Pl, sizeof(float) * 12); memcpy(hs.Pr, Pr, sizeof(float) * 12);
+    HIPCHK(hipMemcpyAsync(c->d.tl0, pts_l, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d.tr0, pts_r, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    if ((rc = set_state(c, hs)) != SVO_OK) return rc;
+    launch_triangulate(c->d, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(xyz, c->d.world, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SVO_OK;
+}
+
+extern "C" int svo_camera_to_world(int device, const float K[9], int n, const float* cam_pts, const float* world_pts,
+                                   double R[9], double t[3], int* inliers, int* n_inliers, int* success,
+                                   int ransac_iterations, float reproj_error, float confidence, int* iters_run) {
+    if (!K || !R || !t || !n_inliers || !success || n < 0 || (n > 0 && (!cam_pts || !world_pts))) return fail_arg("bad arguments");
+    *n_inliers = 0; *success = 0; if (iters_run) *iters_run = 0;
+    if (n < 6) return SVO_OK;      // fewer points than the 5-point kernel can sample from: the reference guards with >15 (vo.cpp:82)
+    svo_config cfg; svo_config_default(&cfg);
+    cfg.ransac_iterations = ransac_iterations > 1 ? ransac_iterations : 1;
+    cfg.ransac_reprojection_error = reproj_error; cfg.ransac_confidence = confidence;
+    cfg.features_threshold = 0;                                                  // cameraToWorld itself has no inlier-count gate
+    cfg.max_translation_norm = 1e300; cfg.max_rotation_norm = 1e300;             // nor motion gates
+    CtxGuard g; int rc = ctx_create(&cfg, device, 1, 64, 64, n, &g.c); if (rc != SVO_OK) return rc;
+    svo_context* c = g.c;
+    SeqState hs; memset(&hs, 0, sizeof(hs));
+    hs.active = 1; hs.fail_reason = 0; hs.n_tracks = n; hs.n_feat = n; hs.feat_buf = 0;
+    memcpy(hs.K, K, sizeof(float) * 9); memcpy(hs.R, R, sizeof(double) * 9); memcpy(hs.t, t, sizeof(double) * 3);
+    HIPCHK(hipMemcpyAsync(c->d.tl1, cam_pts, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d.world, world_pts, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    if ((rc = set_state(c, hs)) != SVO_OK) return rc;
+    launch_pnp(c->d, c->stream);
+    HIPCHK(hipGetLastError());
+    if ((rc = read_state(c, 0, &hs)) != SVO_OK) return rc;
+    if (iters_run) *iters_run = hs.pnp_iters;
+    if (hs.pnp_best < 0) return SVO_OK;                                          // success = false: R, t untouched (vo.cpp:307-311)
+    memcpy(R, hs.R, sizeof(double) * 9); memcpy(t, hs.t, sizeof(double) * 3);
+    *success = 1; *n_inliers = hs.n_inliers;
+    if (inliers && hs.n_inliers > 0)
+        HIPCHK(hipMemcpy(inliers, c->d.inl_idx, sizeof(int) * hs.n_inliers, hipMemcpyDeviceToHost));
+    return SVO_OK;
+}
+
+extern "C" int svo_inverse_transform(const double R[9], const double t[3], double T[16]) {
+    if (!R || !t || !T) return fail_arg("null argument");
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T[4 * i + j] = R[3 * j + i];
+        T[4 * i + 3] = -(R[i] * t[0] + R[3 + i] * t[1] + R[6 + i] * t[2]);
+    }
+    T[12] = T[13] = T[14] = 0; T[15] = 1;
+    return SVO_OK;
+}

@@ -1,0 +1,92 @@
+// svo_internal.hpp — shared declarations for the HIP translation units of libsvo_hip.so.
+// Product code (gfx950 only).  Never includes anything from oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/svo.h"
+
+#define SVO_MAX_LEVELS 8
+#define SVO_RING 8            // results ring / max frames in flight
+#define SVO_MAX_WIN 31
+
+struct LevelInfo { int w, h, off; };          // off: byte offset of the level inside one pyramid buffer
+struct Geometry {
+    int W, H;
+    int nlevels;                              // levels actually built (cv::buildOpticalFlowPyramid stop rule)
+    LevelInfo lv[SVO_MAX_LEVELS];
+    int pyr_bytes;                            // bytes of one pyramid (all levels, tightly packed, 16-B aligned levels)
+};
+
+// Device-resident state of one sequence = the members of the reference's VisualOdometry (include/vo.h:233-269).
+struct SeqState {
+    int frame_id;                             // vo.h:234
+    int slot_t1, slot_img_t0, slot_pyr_t0;    // which of the 3 pyramid slots holds T1 / imageLeftT0_ / lastLeftPyramid
+    int active;                               // this frame runs matching (frame_id > 0 when the frame began)
+    int feat_buf;                             // which half of the feature double-buffer is current
+    int n_feat;                               // currentVOFeatures.size()
+    int n_old;                                // feature count offered to the bucket grid by the current detection pass
+    int do_second;                            // second FAST pass at threshold/4 required (vo.cpp:327)
+    int n_lk;                                 // points entering circularMatching
+    int n_tracks;                             // tracks after circular + bounds compaction
+    int n_circ;                               // tracks after circular mask only (vo.cpp:239)
+    int fail_reason;
+    int pnp_best, pnp_iters, pnp_good;
+    int n_inliers;
+    int ok;
+    double R[9], t[3], last_T[16];            // vo.h:266-268
+    float Pl[12], Pr[12], K[9];               // vo.h:273, :236
+    svo_frame_stats stats;
+};
+
+struct FrameResult { double T[16]; int ok; svo_frame_stats stats; };
+
+// All device buffers of a context (B sequences, capacity CAP features each).
+struct DevBuffers {
+    int B, CAP, NB;                            // NB = buckets_along_height * buckets_along_width
+    int K;                                     // ransac_iterations
+    Geometry geom;
+    svo_config cfg;
+    int bucket_h, bucket_w;
+    SeqState* st;                              // [B]
+    uint8_t* pyr;                              // [B][3 slots][2 cams][pyr_bytes]
+    float2* feat_xy[2]; int* feat_age[2]; int* feat_str[2];   // [B][CAP] each, double-buffered
+    unsigned long long* bucket_keys;           // [B][NB]
+    float2 *pl0, *pl1, *pr1, *pr0, *plc;       // [B][CAP] raw LK outputs
+    uint8_t* okmask;                           // [B][CAP] bit0 circular ok, bit1 in-bounds
+    float2 *tl0, *tr0, *tl1, *tr1;             // [B][CAP] compacted tracks
+    float* world;                              // [B][CAP][3]
+    uint8_t* inlier;                           // [B][CAP]
+    int* subsets;                              // [B][K][5]
+    double* hyp;                               // [B][K][12]  (R row-major, t)
+    int* hyp_good;                             // [B][K]
+    int* inl_idx;                              // [B][CAP]
+    FrameResult* results;                      // [SVO_RING][B]
+    const uint8_t** img_ptrs;                  // [SVO_RING][2][B] device array of source image pointers
+};
+
+__host__ __device__ inline size_t pyr_index(const DevBuffers& d, int seq, int slot, int cam) {
+    return ((size_t)(seq * 3 + slot) * 2 + cam) * (size_t)d.geom.pyr_bytes;
+}
+
+// ---- launchers (each enqueues on `s`; none synchronises) ----
+void launch_frame_begin(const DevBuffers& d, hipStream_t s);
+void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs /* [2][B] device array */, int stride, hipStream_t s);
+void launch_pyramid(const DevBuffers& d, hipStream_t s);
+void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s);   // pass 0: FAST_THRESHOLD, pass 1: /4 if needed; th_override >= 0 replaces it
+void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t s);      // grid_n = max features that can enter LK
+void launch_compact(const DevBuffers& d, hipStream_t s);
+void launch_triangulate(const DevBuffers& d, hipStream_t s);
+void launch_pnp(const DevBuffers& d, hipStream_t s);
+void launch_frame_end(const DevBuffers& d, int ring_slot, hipStream_t s);
+
+// stage helpers
+void launch_fast_score_map(const uint8_t* img_dev, int w, int h, int threshold, uint8_t* score_dev, hipStream_t s);
+void launch_score_compact(const uint8_t* score_dev, int w, int h, int cap, int* row_counts_dev, float2* xy_dev, float* resp_dev, int* n_dev, hipStream_t s);
+void launch_bucket_general(int img_w, int img_h, int n, const float2* xy, const int* ages, const int* strs,
+                           int bah, int baw, int start_row, int per_bucket, int age_thr, int fast_thr,
+                           float2* slot_xy, int* slot_age, int* slot_str, int* slot_n,
+                           float2* out_xy, int* out_age, int* out_str, int* n_out, hipStream_t s);
+void launch_lk_single(const DevBuffers& d, int slotA, int camA, int slotB, int camB, int n, const float2* prev, float2* next,
+                      uint8_t* status, hipStream_t s);
+void launch_find_close(int n, const float2* a, const float2* b, float thr, uint8_t* ok, hipStream_t s);
+bool lk_window_supported(int win);

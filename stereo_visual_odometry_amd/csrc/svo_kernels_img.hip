@@ -1,0 +1,503 @@
+// svo_kernels_img.hip — frame bookkeeping, ingest, pyrDown, FAST-9/16 + NMS, bucketing, compaction.
+// gfx950 (wave64).  All integer / byte work: HBM-bound by design, no MFMA.
+//
+// Behaviour follows the reference call sites (cited per kernel); the arithmetic of the OpenCV
+// functions they call is restated independently, not translated.
+#include "svo_internal.hpp"
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
+// ------------------------------------------------------------------------------------------------
+// frame begin / end: the slot bookkeeping of stereo_callback (vo.cpp:47-56, 74-75) and of the
+// pyramid cache in circularMatching (vo.cpp:179-181 vs 231-232: the cache is NOT refreshed when
+// there were no points to match — the "stale pyramid" quirk).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_frame_begin(DevBuffers d) {
+    int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= d.B) return;
+    SeqState& s = d.st[seq];
+    s.active = s.frame_id > 0;
+    int t1 = 0;
+    for (int c = 0; c < 3; c++) if (c != s.slot_img_t0 && c != s.slot_pyr_t0) { t1 = c; break; }
+    s.slot_t1 = t1;
+    s.do_second = 0; s.n_lk = 0; s.n_tracks = 0; s.n_circ = 0; s.n_inliers = 0; s.ok = 0;
+    s.pnp_best = -1; s.pnp_iters = 0; s.pnp_good = 0;
+    s.fail_reason = s.active ? 0 : 1;
+    svo_frame_stats z = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    s.stats = z;
+}
+
+__global__ void k_frame_end(DevBuffers d, int ring_slot) {
+    int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= d.B) return;
+    SeqState& s = d.st[seq];
+    s.slot_img_t0 = s.slot_t1;                                   // vo.cpp:48-49 / 74-75
+    if (!s.active || s.n_lk > 0) s.slot_pyr_t0 = s.slot_t1;      // vo.cpp:50-53 / 231-232 (skipped on the early return :179-181)
+    s.frame_id++;
+    FrameResult& r = d.results[(size_t)ring_slot * d.B + seq];
+    for (int i = 0; i < 16; i++) r.T[i] = s.last_T[i];           // fail_result = last_transform (vo.cpp:43-44); on success last_T was just updated
+    r.ok = s.ok;
+    s.stats.fail_reason = s.fail_reason;
+    s.stats.n_features_out = s.n_feat;
+    s.stats.n_into_lk = s.n_lk;
+    s.stats.n_after_circular = s.n_circ;
+    s.stats.n_after_bounds = s.n_tracks;
+    s.stats.n_inliers = s.n_inliers;
+    s.stats.ransac_iters = s.pnp_iters;
+    r.stats = s.stats;
+}
+
+void launch_frame_begin(const DevBuffers& d, hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_begin, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
+}
+void launch_frame_end(const DevBuffers& d, int ring_slot, hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_end, dim3((d.B + 63) / 64), dim3(64), 0, st, d, ring_slot);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ingest: copy the caller's two images into level 0 of the T1 pyramid slot (the deep copies of
+// vo.cpp:74-75 / the level-0 copy of cv::buildOpticalFlowPyramid).  One thread = 4 pixels of a row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ingest(DevBuffers d, const uint8_t* const* srcs, int stride) {
+    const int seq = blockIdx.z, cam = blockIdx.y;
+    const int W = d.geom.W, H = d.geom.H;
+    const int quads_per_row = (W + 3) >> 2;
+    const int total = quads_per_row * H;
+    const uint8_t* src = srcs[cam * d.B + seq];
+    uint8_t* dst = d.pyr + pyr_index(d, seq, d.st[seq].slot_t1, cam);
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+        int y = q / quads_per_row, x = (q - y * quads_per_row) << 2;
+        const uint8_t* sp = src + (size_t)y * stride + x;
+        uint8_t* dp = dst + (size_t)y * W + x;
+        int n = W - x < 4 ? W - x : 4;
+        for (int k = 0; k < n; k++) dp[k] = sp[k];
+    }
+}
+
+void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride, hipStream_t st) {
+    int total = ((d.geom.W + 3) >> 2) * d.geom.H;
+    int gx = (total + 255) / 256; if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_ingest, dim3(gx, 2, d.B), dim3(256), 0, st, d, left_right_dev_ptrs, stride);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pyrDown (the level loop of cv::buildOpticalFlowPyramid, vo.cpp:50,52,200,201):
+// dst(x,y) = (sum_{i,j} k_i k_j src(2x+i-2, 2y+j-2) + 128) >> 8, k = [1 4 6 4 1], REFLECT_101.
+// 32x8 output tile per 256-thread block, source tile staged in LDS, separable in two LDS passes.
+// ------------------------------------------------------------------------------------------------
+#define PD_TW 32
+#define PD_TH 8
+__global__ __launch_bounds__(256) void k_pyrdown(DevBuffers d, int level) {
+    const int seq = blockIdx.z / 2, cam = blockIdx.z & 1;
+    const LevelInfo ls = d.geom.lv[level - 1], ld = d.geom.lv[level];
+    uint8_t* base = d.pyr + pyr_index(d, seq, d.st[seq].slot_t1, cam);
+    const uint8_t* src = base + ls.off;
+    uint8_t* dst = base + ld.off;
+    constexpr int SW = 2 * PD_TW + 3, SH = 2 * PD_TH + 3;        // 67 x 19 source tile
+    __shared__ uint8_t tile[SH][SW + 1];
+    __shared__ unsigned short hrow[SH][PD_TW];                   // horizontal pass result (<= 16*255)
+    const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
+    const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
+    for (int i = threadIdx.x; i < SW * SH; i += 256) {
+        int ty = i / SW, tx = i - ty * SW;
+        tile[ty][tx] = src[(size_t)reflect101(sy0 + ty, ls.h) * ls.w + reflect101(sx0 + tx, ls.w)];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SH * PD_TW; i += 256) {
+        int ty = i / PD_TW, x = i - ty * PD_TW;
+        const uint8_t* r = &tile[ty][2 * x];
+        hrow[ty][x] = (unsigned short)(r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4]);
+    }
+    __syncthreads();
+    {
+        int y = threadIdx.x / PD_TW, x = threadIdx.x - y * PD_TW;
+        int gx = ox + x, gy = oy + y;
+        if (gx < ld.w && gy < ld.h) {
+            int v = hrow[2 * y + 2][x] * 6 + (hrow[2 * y + 1][x] + hrow[2 * y + 3][x]) * 4 + hrow[2 * y][x] + hrow[2 * y + 4][x];
+            dst[(size_t)gy * ld.w + gx] = (uint8_t)((v + 128) >> 8);
+        }
+    }
+}
+
+void launch_pyramid(const DevBuffers& d, hipStream_t st) {
+    for (int l = 1; l < d.geom.nlevels; l++) {
+        dim3 g((d.geom.lv[l].w + PD_TW - 1) / PD_TW, (d.geom.lv[l].h + PD_TH - 1) / PD_TH, d.B * 2);
+        hipLaunchKernelGGL(k_pyrdown, g, dim3(256), 0, st, d, l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16 score + strict 3x3 NMS (cv::FAST(img, kps, th, true) at feature_set.cpp:61).
+// 64x16 output tile per 256-thread block: 72x24 pixels staged in LDS (3-px circle halo + 1-px NMS
+// halo), u8 scores for the 66x18 ring-extended tile in LDS, then NMS.  Survivors either go straight
+// into the bucket grid with one 64-bit atomicMax (frame pipeline) or into a dense score map (stage API).
+// ------------------------------------------------------------------------------------------------
+#define FT_W 64
+#define FT_H 16
+#define FT_PW (FT_W + 8)
+#define FT_PH (FT_H + 8)
+#define FT_SW (FT_W + 2)
+#define FT_SH (FT_H + 2)
+
+// Bresenham circle r=3 in OpenCV order
+#define CIRC_DX {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1}
+#define CIRC_DY {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3}
+
+// >= 9 contiguous set bits in a circular 16-bit mask
+__device__ __forceinline__ bool run9(unsigned m) {
+    unsigned m2 = m | (m << 16);
+    unsigned a = m2 & (m2 >> 1);
+    unsigned b = a & (a >> 2);
+    unsigned c = b & (b >> 4);
+    return ((c & (m2 >> 8)) & 0xFFFFu) != 0;
+}
+
+// score of the pixel at LDS position (py,px): 0 if not a corner, else max(t, best 9-arc min|diff|) - 1
+__device__ __forceinline__ int fast_score(const uint8_t (*pix)[FT_PW + 4], int py, int px, int t) {
+    constexpr int cdx[16] = CIRC_DX, cdy[16] = CIRC_DY;
+    int v = pix[py][px];
+    int dd[16];
+    unsigned mb = 0, md = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int p = pix[py + cdy[k]][px + cdx[k]];
+        dd[k] = v - p;
+        md |= (unsigned)(p < v - t) << k;       // darker than centre
+        mb |= (unsigned)(p > v + t) << k;       // brighter
+    }
+    if (!run9(mb) && !run9(md)) return 0;
+    // sliding 9-window minimum / maximum over the circular sequence
+    int best = t, worst = -t;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int mn = dd[k], mx = dd[k];
+#pragma unroll
+        for (int j = 1; j < 9; j++) { int e = dd[(k + j) & 15]; mn = e < mn ? e : mn; mx = e > mx ? e : mx; }
+        best = mn > best ? mn : best;           // a0 = max(a0, arc-min of (v - p))
+        worst = mx < worst ? mx : worst;        // b0 = min(b0, arc-max of (v - p))
+    }
+    // cornerScore: a0 from the "centre brighter" side, then b0 = min(-a0, arc-max...) ; score = -b0 - 1
+    int b0 = -best;
+    b0 = worst < b0 ? worst : b0;
+    return -b0 - 1;
+}
+
+struct BucketGrid { int bucket_h, bucket_w, bah, baw, start_row, age_thr, fast_thr; };
+
+__device__ __forceinline__ unsigned long long make_bucket_key(int score, unsigned order, int strength) {
+    int s = score + 32768; s = s < 1 ? 1 : (s > 65535 ? 65535 : s);
+    return ((unsigned long long)s << 48) | ((unsigned long long)(0xFFFFFFFFu - order) << 16) | (unsigned long long)(strength & 0xFFFF);
+}
+
+template <bool TO_BUCKETS>
+__global__ __launch_bounds__(256) void k_fast(const uint8_t* img_single, int w_single, int h_single, uint8_t* score_out,
+                                              DevBuffers d, int pass, int threshold) {
+    __shared__ uint8_t pix[FT_PH][FT_PW + 4];
+    __shared__ uint8_t sc[FT_SH][FT_SW + 2];
+    const int seq = blockIdx.z;
+    int W, H; const uint8_t* img;
+    if (TO_BUCKETS) {
+        const SeqState& s = d.st[seq];
+        if (pass == 0 ? !s.active : !s.do_second) return;
+        W = d.geom.W; H = d.geom.H;
+        img = d.pyr + pyr_index(d, seq, s.slot_img_t0, 0);       // FAST runs on the PREVIOUS left image (vo.cpp:325)
+    } else { W = w_single; H = h_single; img = img_single; }
+    if (threshold < 0) threshold = 0;
+    if (threshold > 255) threshold = 255;
+    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    for (int i = threadIdx.x; i < FT_PH * FT_PW; i += 256) {
+        int py = i / FT_PW, px = i - py * FT_PW;
+        int gx = x0 - 4 + px, gy = y0 - 4 + py;
+        pix[py][px] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(size_t)gy * W + gx] : (uint8_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < FT_SH * FT_SW; i += 256) {
+        int sy = i / FT_SW, sx = i - sy * FT_SW;
+        int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
+        int s = 0;
+        if (gx >= 3 && gx < W - 3 && gy >= 3 && gy < H - 3) s = fast_score(pix, sy + 3, sx + 3, threshold);
+        sc[sy][sx] = (uint8_t)s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < FT_W * FT_H; i += 256) {
+        int oy = i / FT_W, ox = i - oy * FT_W;
+        int gx = x0 + ox, gy = y0 + oy;
+        if (gx >= W || gy >= H) continue;
+        int s = sc[oy + 1][ox + 1];
+        bool keep = s != 0 &&
+                    s > sc[oy + 1][ox] && s > sc[oy + 1][ox + 2] &&
+                    s > sc[oy][ox] && s > sc[oy][ox + 1] && s > sc[oy][ox + 2] &&
+                    s > sc[oy + 2][ox] && s > sc[oy + 2][ox + 1] && s > sc[oy + 2][ox + 2];
+        if (TO_BUCKETS) {
+            if (keep) {
+                // feature_set.cpp:83-87 (age 0, strength = response) + :122-124 bucket index + Bucket::add_feature (:20-53)
+                int bh = (int)((float)gy / (float)d.bucket_h), bw = (int)((float)gx / (float)d.bucket_w);
+                if (bh >= d.cfg.bucket_start_row && bh < d.cfg.buckets_along_height && bw < d.cfg.buckets_along_width && 0 < d.cfg.age_threshold) {
+                    int score = 0 + (s - d.cfg.fast_threshold) / 20;                       // feature_set.cpp:16-18
+                    unsigned order = (unsigned)d.st[seq].n_old + (unsigned)(gy * W + gx);     // raster rank keeps cv::FAST's output order
+                    atomicMax(&d.bucket_keys[(size_t)seq * d.NB + bh * d.cfg.buckets_along_width + bw], make_bucket_key(score, order, s));
+                }
+            }
+        } else {
+            score_out[(size_t)gy * W + gx] = keep ? (uint8_t)s : (uint8_t)0;
+        }
+    }
+}
+
+void launch_fast_score_map(const uint8_t* img_dev, int w, int h, int threshold, uint8_t* score_dev, hipStream_t st) {
+    DevBuffers dummy = {};
+    dim3 g((w + FT_W - 1) / FT_W, (h + FT_H - 1) / FT_H, 1);
+    hipLaunchKernelGGL(k_fast<false>, g, dim3(256), 0, st, img_dev, w, h, score_dev, dummy, 0, threshold);
+}
+
+// raster-ordered compaction of a score map into keypoints (cv::FAST output order + KeyPoint::convert, feature_set.cpp:62-66)
+__global__ void k_score_row_count(const uint8_t* score, int w, int h, int* row_counts) {
+    int y = blockIdx.x;
+    int cnt = 0;
+    for (int x = threadIdx.x; x < w; x += 64) cnt += score[(size_t)y * w + x] != 0;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (threadIdx.x == 0) row_counts[y] = cnt;
+}
+__global__ void k_scan_rows(int* row_counts, int h, int* n_out) {          // single thread; h is a few hundred
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int acc = 0;
+        for (int y = 0; y < h; y++) { int c = row_counts[y]; row_counts[y] = acc; acc += c; }
+        *n_out = acc;
+    }
+}
+__global__ void k_score_row_emit(const uint8_t* score, int w, int h, const int* row_off, int cap, float2* xy, float* resp) {
+    int y = blockIdx.x;
+    int base = row_off[y];
+    for (int x0 = 0; x0 < w; x0 += 64) {
+        int x = x0 + threadIdx.x;
+        int s = x < w ? score[(size_t)y * w + x] : 0;
+        unsigned long long m = __ballot(s != 0);
+        if (s) {
+            int idx = base + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+            if (idx < cap) { xy[idx] = make_float2((float)x, (float)y); resp[idx] = (float)s; }
+        }
+        base += __popcll(m);
+    }
+}
+void launch_score_compact(const uint8_t* score_dev, int w, int h, int cap, int* row_counts_dev, float2* xy_dev, float* resp_dev, int* n_dev, hipStream_t st) {
+    hipLaunchKernelGGL(k_score_row_count, dim3(h), dim3(64), 0, st, score_dev, w, h, row_counts_dev);
+    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(64), 0, st, row_counts_dev, h, n_dev);
+    hipLaunchKernelGGL(k_score_row_emit, dim3(h), dim3(64), 0, st, score_dev, w, h, row_counts_dev, cap, xy_dev, resp_dev);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bucketing for features_per_bucket == 1 (the reference default, vo.h:65).
+// Bucket::add_feature's "first in, replace the minimum iff strictly better" with one slot is
+// argmax(score) with ties -> lowest input index, i.e. one 64-bit atomicMax per candidate with
+// key = (score, ~input_index, strength).  Input order = existing tracks first, then the new FAST
+// hits in raster order (feature_set.cpp:83-87).  Emission is bucket-raster order (:132-146).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_bucket_clear(DevBuffers d, int pass) {
+    const int seq = blockIdx.y;
+    SeqState& s = d.st[seq];
+    if (pass == 0 ? !s.active : !s.do_second) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.NB; i += gridDim.x * blockDim.x)
+        d.bucket_keys[(size_t)seq * d.NB + i] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) s.n_old = s.n_feat;
+}
+
+__global__ void k_bucket_offer_old(DevBuffers d, int pass) {
+    const int seq = blockIdx.y;
+    const SeqState& s = d.st[seq];
+    if (pass == 0 ? !s.active : !s.do_second) return;
+    const int n = s.n_feat, fb = s.feat_buf;
+    const float2* xy = d.feat_xy[fb] + (size_t)seq * d.CAP;
+    const int* age = d.feat_age[fb] + (size_t)seq * d.CAP;
+    const int* str = d.feat_str[fb] + (size_t)seq * d.CAP;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float2 p = xy[i];
+        int a = age[i], st = str[i];
+        int bh = (int)(p.y / (float)d.bucket_h), bw = (int)(p.x / (float)d.bucket_w);   // feature_set.cpp:122-123
+        if (p.x < 0.f || p.y < 0.f || bh < d.cfg.bucket_start_row || bh >= d.cfg.buckets_along_height || bw >= d.cfg.buckets_along_width) continue;
+        if (a >= d.cfg.age_threshold) continue;                                           // feature_set.cpp:26
+        int score = a + (st - d.cfg.fast_threshold) / 20;
+        atomicMax(&d.bucket_keys[(size_t)seq * d.NB + bh * d.cfg.buckets_along_width + bw], make_bucket_key(score, (unsigned)i, st));
+    }
+}
+
+// one 1024-thread block per sequence: scan the grid in raster order, emit winners
+__global__ __launch_bounds__(1024) void k_bucket_emit(DevBuffers d, int pass) {
+    const int seq = blockIdx.x;
+    SeqState& s = d.st[seq];
+    if (pass == 0 ? !s.active : !s.do_second) return;
+    __shared__ int wave_tot[16];
+    __shared__ int s_total;
+    const int fb = s.feat_buf, nb = d.NB, n_old = s.n_old, W = d.geom.W;
+    const unsigned long long* keys = d.bucket_keys + (size_t)seq * nb;
+    const float2* oxy = d.feat_xy[fb] + (size_t)seq * d.CAP;
+    const int* oage = d.feat_age[fb] + (size_t)seq * d.CAP;
+    const int* ostr = d.feat_str[fb] + (size_t)seq * d.CAP;
+    float2* nxy = d.feat_xy[fb ^ 1] + (size_t)seq * d.CAP;
+    int* nage = d.feat_age[fb ^ 1] + (size_t)seq * d.CAP;
+    int* nstr = d.feat_str[fb ^ 1] + (size_t)seq * d.CAP;
+    const int chunk = (nb + 1023) / 1024;
+    const int b0 = threadIdx.x * chunk, b1 = (b0 + chunk < nb) ? b0 + chunk : nb;
+    int cnt = 0;
+    for (int b = b0; b < b1; b++) cnt += keys[b] != 0ull;
+    // block exclusive scan of cnt
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < 16; i++) { int t = wave_tot[i]; wave_tot[i] = acc; acc += t; } s_total = acc; }
+    __syncthreads();
+    int pos = wave_tot[wv] + incl - cnt;
+    for (int b = b0; b < b1; b++) {
+        unsigned long long k = keys[b];
+        if (k == 0ull) continue;
+        unsigned order = 0xFFFFFFFFu - (unsigned)((k >> 16) & 0xFFFFFFFFull);
+        if (pos < d.CAP) {
+            if (order < (unsigned)n_old) { nxy[pos] = oxy[order]; nage[pos] = oage[order]; nstr[pos] = ostr[order]; }
+            else {
+                unsigned pixi = order - (unsigned)n_old;
+                int y = (int)(pixi / (unsigned)W), x = (int)(pixi - (unsigned)y * (unsigned)W);
+                nxy[pos] = make_float2((float)x, (float)y); nage[pos] = 0; nstr[pos] = (int)(k & 0xFFFFull);
+            }
+        }
+        pos++;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = s_total < d.CAP ? s_total : d.CAP;
+        s.n_feat = total; s.feat_buf = fb ^ 1;
+        s.stats.n_after_detect = total;
+        if (pass == 0) s.do_second = total < d.cfg.pre_matching_feature_threshold;   // vo.cpp:327
+        else s.stats.second_pass = 1;
+    }
+}
+
+void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t st) {
+    int th = pass == 0 ? d.cfg.fast_threshold : d.cfg.fast_threshold / 4;            // vo.cpp:325 / :329-330
+    if (th_override >= 0) th = th_override;
+    hipLaunchKernelGGL(k_bucket_clear, dim3((d.NB + 1023) / 1024, d.B), dim3(1024), 0, st, d, pass);
+    hipLaunchKernelGGL(k_bucket_offer_old, dim3((d.CAP + 255) / 256, d.B), dim3(256), 0, st, d, pass);
+    dim3 g((d.geom.W + FT_W - 1) / FT_W, (d.geom.H + FT_H - 1) / FT_H, d.B);
+    hipLaunchKernelGGL(k_fast<true>, g, dim3(256), 0, st, (const uint8_t*)nullptr, 0, 0, (uint8_t*)nullptr, d, pass, th);
+    hipLaunchKernelGGL(k_bucket_emit, dim3(d.B), dim3(1024), 0, st, d, pass);
+}
+
+// ------------------------------------------------------------------------------------------------
+// General bucketing (any features_per_bucket): one thread per bucket walks the inputs in order and
+// applies Bucket::add_feature verbatim in behaviour (feature_set.cpp:20-53).  O(N * buckets): only
+// the reference's unit tests use per-bucket capacities other than 1 (main.cpp:125,152-157).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_bucket_general(int img_w, int img_h, int n, const float2* xy, const int* ages, const int* strs,
+                                 int bah, int baw, int start_row, int per_bucket, int age_thr, int fast_thr,
+                                 float2* slot_xy, int* slot_age, int* slot_str, int* slot_n) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= bah * baw) return;
+    int bucket_h = (img_h + bah - 1) / bah, bucket_w = (img_w + baw - 1) / baw;      // feature_set.cpp:91-93,103-104
+    int cap = (b / baw) >= start_row ? per_bucket : 0;                               // :113-116
+    float2* sx = slot_xy + (size_t)b * per_bucket; int* sa = slot_age + (size_t)b * per_bucket; int* ss = slot_str + (size_t)b * per_bucket;
+    int cnt = 0;
+    for (int i = 0; i < n && cap > 0; i++) {
+        float2 p = xy[i];
+        int bh = (int)(p.y / (float)bucket_h), bw = (int)(p.x / (float)bucket_w);
+        if (bh < 0 || bh >= bah || bw < 0 || bw >= baw || bh * baw + bw != b) continue;
+        int a = ages[i], st = strs[i];
+        if (a >= age_thr) continue;
+        if (cnt < cap) { sx[cnt] = p; sa[cnt] = a; ss[cnt] = st; cnt++; }
+        else {
+            int score = a + (st - fast_thr) / 20;
+            int smin = sa[0] + (ss[0] - fast_thr) / 20, imin = 0;
+            for (int k = 1; k < cnt; k++) { int c = sa[k] + (ss[k] - fast_thr) / 20; if (c < smin) { smin = c; imin = k; } }
+            if (score > smin) { sx[imin] = p; sa[imin] = a; ss[imin] = st; }
+        }
+    }
+    slot_n[b] = cnt;
+}
+__global__ void k_bucket_general_emit(int nb, int per_bucket, const float2* slot_xy, const int* slot_age, const int* slot_str, const int* slot_n,
+                                      float2* out_xy, int* out_age, int* out_str, int* n_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;                                 // test-sized inputs: serial emit keeps bucket-raster order
+    int m = 0;
+    for (int b = 0; b < nb; b++)
+        for (int k = 0; k < slot_n[b]; k++) {
+            out_xy[m] = slot_xy[(size_t)b * per_bucket + k]; out_age[m] = slot_age[(size_t)b * per_bucket + k]; out_str[m] = slot_str[(size_t)b * per_bucket + k]; m++;
+        }
+    *n_out = m;
+}
+void launch_bucket_general(int img_w, int img_h, int n, const float2* xy, const int* ages, const int* strs,
+                           int bah, int baw, int start_row, int per_bucket, int age_thr, int fast_thr,
+                           float2* slot_xy, int* slot_age, int* slot_str, int* slot_n,
+                           float2* out_xy, int* out_age, int* out_str, int* n_out, hipStream_t st) {
+    int nb = bah * baw;
+    hipLaunchKernelGGL(k_bucket_general, dim3((nb + 255) / 256), dim3(256), 0, st, img_w, img_h, n, xy, ages, strs, bah, baw, start_row,
+                       per_bucket, age_thr, fast_thr, slot_xy, slot_age, slot_str, slot_n);
+    hipLaunchKernelGGL(k_bucket_general_emit, dim3(1), dim3(64), 0, st, nb, per_bucket, slot_xy, slot_age, slot_str, slot_n, out_xy, out_age, out_str, n_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stable compaction after circular matching + in-bounds mask (deletePointsWithFailureStatus /
+// deleteFeaturesWithFailureStatus, vo.cpp:144-168, called at :233-238 and :360-364), fused with
+// ages[i] += 1 (vo.cpp:70-72) and the "too few tracks" gate (vo.cpp:82-84).
+// One 1024-thread block per sequence, order-preserving prefix sum.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_compact(DevBuffers d) {
+    const int seq = blockIdx.x;
+    SeqState& s = d.st[seq];
+    if (!s.active) return;
+    __shared__ int wave_tot[16], wave_tot_c[16];
+    __shared__ int s_total, s_total_c;
+    const int n = s.n_lk, fb = s.feat_buf;
+    const size_t o = (size_t)seq * d.CAP;
+    const int chunk = (n + 1023) / 1024;
+    const int i0 = threadIdx.x * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
+    int cnt = 0, cntc = 0;
+    for (int i = i0; i < i1; i++) { uint8_t m = d.okmask[o + i]; cnt += (m == 3); cntc += (m & 1); }
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = cnt, inclc = cntc;
+    for (int k = 1; k < 64; k <<= 1) { int t = __shfl_up(incl, k), tc = __shfl_up(inclc, k); if (lane >= k) { incl += t; inclc += tc; } }
+    if (lane == 63) { wave_tot[wv] = incl; wave_tot_c[wv] = inclc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0, accc = 0;
+        for (int i = 0; i < 16; i++) { int t = wave_tot[i]; wave_tot[i] = acc; acc += t; accc += wave_tot_c[i]; }
+        s_total = acc; s_total_c = accc;
+    }
+    __syncthreads();
+    int pos = wave_tot[wv] + incl - cnt;
+    const float2* fxy = d.feat_xy[fb] + o; const int* fage = d.feat_age[fb] + o; const int* fstr = d.feat_str[fb] + o;
+    float2* nxy = d.feat_xy[fb ^ 1] + o; int* nage = d.feat_age[fb ^ 1] + o; int* nstr = d.feat_str[fb ^ 1] + o;
+    for (int i = i0; i < i1; i++) {
+        if (d.okmask[o + i] != 3) continue;
+        d.tl0[o + pos] = d.pl0[o + i]; d.tl1[o + pos] = d.pl1[o + i];
+        d.tr1[o + pos] = d.pr1[o + i]; d.tr0[o + pos] = d.pr0[o + i];
+        nxy[pos] = fxy[i]; nage[pos] = fage[i] + 1; nstr[pos] = fstr[i];
+        pos++;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (n > 0) {
+            s.n_tracks = s_total; s.n_circ = s_total_c; s.n_feat = s_total; s.feat_buf = fb ^ 1;
+        } else {
+            s.n_tracks = 0; s.n_circ = 0; s.n_feat = 0;           // empty feature set: circularMatching returned early (vo.cpp:179-181)
+        }
+        int thr = d.cfg.features_threshold > 4 ? d.cfg.features_threshold : 4;
+        if (s.n_tracks <= thr) s.fail_reason = 2;                  // vo.cpp:82-84
+    }
+}
+void launch_compact(const DevBuffers& d, hipStream_t st) {
+    hipLaunchKernelGGL(k_compact, dim3(d.B), dim3(1024), 0, st, d);
+}
+
+// findClosePoints (vo.cpp:265-280) as a stand-alone stage
+__global__ void k_find_close(int n, const float2* a, const float2* b, float thr, uint8_t* ok) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float dx = fabsf(a[i].x - b[i].x), dy = fabsf(a[i].y - b[i].y);
+    float off = (dx < dy) ? dy : dx;
+    ok[i] = off > thr ? 0 : 1;
+}
+void launch_find_close(int n, const float2* a, const float2* b, float thr, uint8_t* ok, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_find_close, dim3((n + 255) / 256), dim3(256), 0, st, n, a, b, thr, ok);
+}

@@ -1,0 +1,558 @@
+// svo_kernels_pnp.hip — stereo triangulation and RANSAC-PnP on the GPU (gfx950).
+//
+// Replaces, for the reference call sites in src/vo.cpp:
+//   :89-94   cv::triangulatePoints + cv::convertPointsFromHomogeneous      -> k_triangulate
+//   :282-313 cameraToWorld = cv::solvePnPRansac(.., ITERATIVE, useExtrinsicGuess) -> k_pnp_subsets,
+//            k_pnp_epnp, k_pnp_score, k_pnp_final
+//   :115-136 inlier feature update, motion gates, getInverseTransform       -> k_pnp_final
+//
+// RANSAC is restructured for the GPU: OpenCV's loop is sequential only through the adaptive
+// iteration count, and its RNG draws do not depend on model quality.  So all K minimal subsets are
+// drawn up front with the same MWC generator and seed, all K EPnP hypotheses are solved and scored
+// in parallel (the hypothesis-score loop is K x N_t independent projections, popcount-reduced), and
+// one thread then replays the accept / shrink rule over the K inlier counts — the same winner the
+// serial loop would pick.  f64 throughout; hypothesis + scoring use only IEEE-exact operations so
+// the inlier mask is bit-reproducible; the final Levenberg–Marquardt refine runs in one workgroup.
+#include "svo_internal.hpp"
+#include "svo_linalg.hpp"
+
+static __device__ __forceinline__ bool seq_live(const SeqState& s) { return s.active && s.fail_reason == 0; }
+
+// ------------------------------------------------------------------------------------------------ triangulation
+__global__ __launch_bounds__(64) void k_triangulate(DevBuffers d) {
+    const int seq = blockIdx.y;
+    const SeqState& s = d.st[seq];
+    if (!seq_live(s)) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n_tracks) return;
+    const size_t o = (size_t)seq * d.CAP + i;
+    const float2 pl = d.tl0[o], pr = d.tr0[o];
+    double A[16], Wv[4], Ut[16], Vt[16];
+    const double xl = pl.x, yl = pl.y, xr = pr.x, yr = pr.y;
+    for (int k = 0; k < 4; k++) {
+        A[0 * 4 + k] = xl * (double)s.Pl[8 + k] - (double)s.Pl[0 + k];
+        A[1 * 4 + k] = yl * (double)s.Pl[8 + k] - (double)s.Pl[4 + k];
+        A[2 * 4 + k] = xr * (double)s.Pr[8 + k] - (double)s.Pr[0 + k];
+        A[3 * 4 + k] = yr * (double)s.Pr[8 + k] - (double)s.Pr[4 + k];
+    }
+    svd_rm<4, 4>(A, Wv, Ut, Vt);
+    const float X = (float)Vt[12], Y = (float)Vt[13], Z = (float)Vt[14], Wh = (float)Vt[15];   // 4xN result is CV_32F
+    const float scale = Wh != 0.f ? 1.f / Wh : 1.f;                                             // convertPointsFromHomogeneous
+    d.world[3 * o] = X * scale; d.world[3 * o + 1] = Y * scale; d.world[3 * o + 2] = Z * scale;
+}
+void launch_triangulate(const DevBuffers& d, hipStream_t st) {
+    hipLaunchKernelGGL(k_triangulate, dim3((d.CAP + 63) / 64, d.B), dim3(64), 0, st, d);
+}
+
+// ------------------------------------------------------------------------------------------------ subsets (cv::RNG, getSubset)
+__global__ void k_pnp_subsets(DevBuffers d) {
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= d.B) return;
+    const SeqState& s = d.st[seq];
+    if (!seq_live(s)) return;
+    const unsigned n = (unsigned)s.n_tracks;
+    unsigned long long state = 0xFFFFFFFFFFFFFFFFull;                // RNG rng((uint64)-1)
+    int* out = d.subsets + (size_t)seq * d.K * 5;
+    for (int it = 0; it < d.K; it++) {
+        int idx[5];
+        for (int i = 0; i < 5; i++) {
+            int v; bool dup;
+            do {
+                state = (unsigned long long)(unsigned)state * 4164903690ull + (unsigned)(state >> 32);
+                v = (int)((unsigned)state % n);
+                dup = false;
+                for (int k = 0; k < i; k++) dup |= (idx[k] == v);
+            } while (dup);
+            idx[i] = v;
+        }
+        for (int i = 0; i < 5; i++) out[it * 5 + i] = idx[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ EPnP on 5 points
+struct Epnp5 {
+    double fu, fv, uc, vc;
+    double pws[15], us[10], alphas[20], pcs[15];
+    double cws[4][3], ccs[4][3];
+};
+static __device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static __device__ __forceinline__ double dist2(const double* a, const double* b) {
+    return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+}
+
+static __device__ double epnp_compute_R_and_t(Epnp5& e, const double* vt, const double* betas, double R[9], double t[3]) {
+    const int n = 5;
+    for (int i = 0; i < 4; i++) e.ccs[i][0] = e.ccs[i][1] = e.ccs[i][2] = 0.0;
+    for (int i = 0; i < 4; i++) {
+        const double* v = vt + 12 * (11 - i);
+        for (int j = 0; j < 4; j++) for (int k = 0; k < 3; k++) e.ccs[j][k] += betas[i] * v[3 * j + k];
+    }
+    for (int i = 0; i < n; i++) {
+        const double* a = e.alphas + 4 * i; double* pc = e.pcs + 3 * i;
+        for (int j = 0; j < 3; j++) pc[j] = a[0] * e.ccs[0][j] + a[1] * e.ccs[1][j] + a[2] * e.ccs[2][j] + a[3] * e.ccs[3][j];
+    }
+    if (e.pcs[2] < 0.0) {
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 3; j++) e.ccs[i][j] = -e.ccs[i][j];
+        for (int i = 0; i < 3 * n; i++) e.pcs[i] = -e.pcs[i];
+    }
+    // estimate_R_and_t (Arun / Horn)
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0}, abt[9], Wv[3], Ut[9], Vt[9];
+    for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) { pc0[j] += e.pcs[3 * i + j]; pw0[j] += e.pws[3 * i + j]; }
+    for (int j = 0; j < 3; j++) { pc0[j] /= n; pw0[j] /= n; }
+    for (int i = 0; i < 9; i++) abt[i] = 0;
+    for (int i = 0; i < n; i++) {
+        const double* pc = e.pcs + 3 * i; const double* pw = e.pws + 3 * i;
+        for (int j = 0; j < 3; j++) {
+            abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
+            abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
+            abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
+        }
+    }
+    svd_rm<3, 3>(abt, Wv, Ut, Vt);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += Ut[k * 3 + i] * Vt[k * 3 + j];
+        R[i * 3 + j] = s;
+    }
+    double det = R[0] * R[4] * R[8] + R[1] * R[5] * R[6] + R[2] * R[3] * R[7]
+               - R[2] * R[4] * R[6] - R[1] * R[3] * R[8] - R[0] * R[5] * R[7];
+    if (det < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
+    for (int i = 0; i < 3; i++) t[i] = pc0[i] - dot3(R + 3 * i, pw0);
+    // reprojection_error
+    double sum2 = 0.0;
+    for (int i = 0; i < n; i++) {
+        const double* pw = e.pws + 3 * i;
+        double Xc = dot3(R, pw) + t[0], Yc = dot3(R + 3, pw) + t[1], inv_Zc = 1.0 / (dot3(R + 6, pw) + t[2]);
+        double ue = e.uc + e.fu * Xc * inv_Zc, ve = e.vc + e.fv * Yc * inv_Zc;
+        double u = e.us[2 * i], v = e.us[2 * i + 1];
+        sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+    }
+    return sum2 / n;
+}
+
+static __device__ void epnp_gauss_newton(const double* L, const double* rho, double betas[4]) {
+    for (int it = 0; it < 5; it++) {
+        double A[24], B[6], X[4];
+        for (int i = 0; i < 6; i++) {
+            const double* rl = L + 10 * i; double* ra = A + 4 * i;
+            ra[0] = 2 * rl[0] * betas[0] + rl[1] * betas[1] + rl[3] * betas[2] + rl[6] * betas[3];
+            ra[1] = rl[1] * betas[0] + 2 * rl[2] * betas[1] + rl[4] * betas[2] + rl[7] * betas[3];
+            ra[2] = rl[3] * betas[0] + rl[4] * betas[1] + 2 * rl[5] * betas[2] + rl[8] * betas[3];
+            ra[3] = rl[6] * betas[0] + rl[7] * betas[1] + rl[8] * betas[2] + 2 * rl[9] * betas[3];
+            B[i] = rho[i] - (rl[0] * betas[0] * betas[0] + rl[1] * betas[0] * betas[1] + rl[2] * betas[1] * betas[1] +
+                             rl[3] * betas[0] * betas[2] + rl[4] * betas[1] * betas[2] + rl[5] * betas[2] * betas[2] +
+                             rl[6] * betas[0] * betas[3] + rl[7] * betas[1] * betas[3] + rl[8] * betas[2] * betas[3] +
+                             rl[9] * betas[3] * betas[3]);
+        }
+        if (!qr_solve<6, 4>(A, B, X)) return;
+        for (int i = 0; i < 4; i++) betas[i] += X[i];
+    }
+}
+
+static __device__ void epnp5(const double* obj, const double* img, double fx, double fy, double cx, double cy, double R[9], double t[3]) {
+    const int n = 5;
+    Epnp5 e;
+    e.fu = fx; e.fv = fy; e.uc = cx; e.vc = cy;
+    for (int i = 0; i < 15; i++) e.pws[i] = obj[i];
+    for (int i = 0; i < 10; i++) e.us[i] = img[i];
+    // control points: centroid + PCA axes
+    for (int j = 0; j < 3; j++) e.cws[0][j] = 0;
+    for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) e.cws[0][j] += e.pws[3 * i + j];
+    for (int j = 0; j < 3; j++) e.cws[0][j] /= n;
+    {
+        double ptp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dc[3], ut[9], vt3[9];
+        for (int i = 0; i < n; i++) {
+            double dd[3];
+            for (int j = 0; j < 3; j++) dd[j] = e.pws[3 * i + j] - e.cws[0][j];
+            for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) ptp[3 * j + k] += dd[j] * dd[k];
+        }
+        svd_rm<3, 3>(ptp, dc, ut, vt3);
+        for (int i = 1; i < 4; i++) {
+            double kk = sqrt(dc[i - 1] / n);
+            for (int j = 0; j < 3; j++) e.cws[i][j] = e.cws[0][j] + kk * vt3[3 * (i - 1) + j];
+        }
+    }
+    {   // barycentric coordinates
+        double cc[9], ci[9];
+        for (int i = 0; i < 3; i++) for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = e.cws[j][i] - e.cws[0][i];
+        inv3_svd(cc, ci);
+        for (int i = 0; i < n; i++) {
+            const double* pi = e.pws + 3 * i; double* a = e.alphas + 4 * i;
+            for (int j = 0; j < 3; j++)
+                a[1 + j] = ci[3 * j] * (pi[0] - e.cws[0][0]) + ci[3 * j + 1] * (pi[1] - e.cws[0][1]) + ci[3 * j + 2] * (pi[2] - e.cws[0][2]);
+            a[0] = 1.0 - a[1] - a[2] - a[3];
+        }
+    }
+    double MtM[144], Wv[12], Ut[144], Vt[144];
+    {
+        double M[120];
+        for (int i = 0; i < n; i++) {
+            double* M1 = M + 24 * i; double* M2 = M1 + 12; const double* as = e.alphas + 4 * i;
+            double u = e.us[2 * i], v = e.us[2 * i + 1];
+            for (int j = 0; j < 4; j++) {
+                M1[3 * j] = as[j] * e.fu; M1[3 * j + 1] = 0.0; M1[3 * j + 2] = as[j] * (e.uc - u);
+                M2[3 * j] = 0.0; M2[3 * j + 1] = as[j] * e.fv; M2[3 * j + 2] = as[j] * (e.vc - v);
+            }
+        }
+        for (int i = 0; i < 12; i++) for (int j = i; j < 12; j++) {
+            double s = 0;
+            for (int k = 0; k < 2 * n; k++) s += M[12 * k + i] * M[12 * k + j];
+            MtM[12 * i + j] = MtM[12 * j + i] = s;
+        }
+    }
+    svd_rm<12, 12>(MtM, Wv, Ut, Vt);
+    double L[60], rho[6];
+    {
+        double dv[4][6][3];
+        for (int i = 0; i < 4; i++) {
+            const double* v = Vt + 12 * (11 - i);
+            int a = 0, b = 1;
+            for (int j = 0; j < 6; j++) {
+                for (int k = 0; k < 3; k++) dv[i][j][k] = v[3 * a + k] - v[3 * b + k];
+                b++;
+                if (b > 3) { a++; b = a + 1; }
+            }
+        }
+        for (int i = 0; i < 6; i++) {
+            double* row = L + 10 * i;
+            row[0] = dot3(dv[0][i], dv[0][i]);
+            row[1] = 2.0 * dot3(dv[0][i], dv[1][i]);
+            row[2] = dot3(dv[1][i], dv[1][i]);
+            row[3] = 2.0 * dot3(dv[0][i], dv[2][i]);
+            row[4] = 2.0 * dot3(dv[1][i], dv[2][i]);
+            row[5] = dot3(dv[2][i], dv[2][i]);
+            row[6] = 2.0 * dot3(dv[0][i], dv[3][i]);
+            row[7] = 2.0 * dot3(dv[1][i], dv[3][i]);
+            row[8] = 2.0 * dot3(dv[2][i], dv[3][i]);
+            row[9] = dot3(dv[3][i], dv[3][i]);
+        }
+        rho[0] = dist2(e.cws[0], e.cws[1]); rho[1] = dist2(e.cws[0], e.cws[2]); rho[2] = dist2(e.cws[0], e.cws[3]);
+        rho[3] = dist2(e.cws[1], e.cws[2]); rho[4] = dist2(e.cws[1], e.cws[3]); rho[5] = dist2(e.cws[2], e.cws[3]);
+    }
+    double be[4], rep[4], Rs[4][9], ts[4][3];
+    {
+        double L4[24], b4[4];
+        for (int i = 0; i < 6; i++) { L4[4 * i] = L[10 * i]; L4[4 * i + 1] = L[10 * i + 1]; L4[4 * i + 2] = L[10 * i + 3]; L4[4 * i + 3] = L[10 * i + 6]; }
+        svd_solve<6, 4>(L4, rho, b4);
+        if (b4[0] < 0) { be[0] = sqrt(-b4[0]); be[1] = -b4[1] / be[0]; be[2] = -b4[2] / be[0]; be[3] = -b4[3] / be[0]; }
+        else { be[0] = sqrt(b4[0]); be[1] = b4[1] / be[0]; be[2] = b4[2] / be[0]; be[3] = b4[3] / be[0]; }
+        epnp_gauss_newton(L, rho, be);
+        rep[1] = epnp_compute_R_and_t(e, Vt, be, Rs[1], ts[1]);
+    }
+    {
+        double L3[18], b3[3];
+        for (int i = 0; i < 6; i++) { L3[3 * i] = L[10 * i]; L3[3 * i + 1] = L[10 * i + 1]; L3[3 * i + 2] = L[10 * i + 2]; }
+        svd_solve<6, 3>(L3, rho, b3);
+        if (b3[0] < 0) { be[0] = sqrt(-b3[0]); be[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
+        else { be[0] = sqrt(b3[0]); be[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
+        if (b3[1] < 0) be[0] = -be[0];
+        be[2] = 0.0; be[3] = 0.0;
+        epnp_gauss_newton(L, rho, be);
+        rep[2] = epnp_compute_R_and_t(e, Vt, be, Rs[2], ts[2]);
+    }
+    {
+        double L5[30], b5[5];
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 5; j++) L5[5 * i + j] = L[10 * i + j];
+        svd_solve<6, 5>(L5, rho, b5);
+        if (b5[0] < 0) { be[0] = sqrt(-b5[0]); be[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
+        else { be[0] = sqrt(b5[0]); be[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
+        if (b5[1] < 0) be[0] = -be[0];
+        be[2] = b5[3] / be[0];
+        be[3] = 0.0;
+        epnp_gauss_newton(L, rho, be);
+        rep[3] = epnp_compute_R_and_t(e, Vt, be, Rs[3], ts[3]);
+    }
+    int N = 1;
+    if (rep[2] < rep[1]) N = 2;
+    if (rep[3] < rep[N]) N = 3;
+    for (int i = 0; i < 9; i++) R[i] = Rs[N][i];
+    for (int i = 0; i < 3; i++) t[i] = ts[N][i];
+}
+
+__global__ __launch_bounds__(64) void k_pnp_epnp(DevBuffers d) {
+    const int seq = blockIdx.y;
+    const SeqState& s = d.st[seq];
+    if (!seq_live(s)) return;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= d.K) return;
+    const size_t o = (size_t)seq * d.CAP;
+    const int* idx = d.subsets + ((size_t)seq * d.K + h) * 5;
+    const double fx = s.K[0], fy = s.K[4], cx = s.K[2], cy = s.K[5];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double obj[15], img[10], R[9], t[3];
+    for (int i = 0; i < 5; i++) {
+        int k = idx[i];
+        obj[3 * i] = d.world[3 * (o + k)]; obj[3 * i + 1] = d.world[3 * (o + k) + 1]; obj[3 * i + 2] = d.world[3 * (o + k) + 2];
+        float2 c = d.tl1[o + k];
+        // undistortPoints on CV_32FC2 with zero distortion (normalise in f64, store f32), then epnp re-applies fu, uc
+        float xn = (float)(((double)c.x - cx) * ifx), yn = (float)(((double)c.y - cy) * ify);
+        img[2 * i] = (double)xn * fx + cx; img[2 * i + 1] = (double)yn * fy + cy;
+    }
+    epnp5(obj, img, fx, fy, cx, cy, R, t);
+    double* out = d.hyp + ((size_t)seq * d.K + h) * 12;
+    for (int i = 0; i < 9; i++) out[i] = R[i];
+    for (int i = 0; i < 3; i++) out[9 + i] = t[i];
+}
+
+// ------------------------------------------------------------------------------------------------ hypothesis scoring
+static __device__ __forceinline__ bool point_is_inlier(const double* Rt, double fx, double fy, double cx, double cy,
+                                                       const float* w3, float2 c, float thr2) {
+    double X = w3[0], Y = w3[1], Z = w3[2];
+    double x = Rt[0] * X + Rt[1] * Y + Rt[2] * Z + Rt[9];
+    double y = Rt[3] * X + Rt[4] * Y + Rt[5] * Z + Rt[10];
+    double z = Rt[6] * X + Rt[7] * Y + Rt[8] * Z + Rt[11];
+    z = z ? 1. / z : 1;
+    x *= z; y *= z;
+    float pu = (float)(x * fx + cx), pv = (float)(y * fy + cy);       // projectPoints: f64 inside, f32 out
+    float du = c.x - pu, dv = c.y - pv;
+    float e = du * du + dv * dv;                                      // computeError, f32
+    return e <= thr2;
+}
+
+__global__ __launch_bounds__(256) void k_pnp_score(DevBuffers d) {
+    const int seq = blockIdx.y, h = blockIdx.x;
+    const SeqState& s = d.st[seq];
+    if (!seq_live(s)) return;
+    __shared__ int total;
+    __shared__ double Rt[12];
+    if (threadIdx.x == 0) total = 0;
+    if (threadIdx.x < 12) Rt[threadIdx.x] = d.hyp[((size_t)seq * d.K + h) * 12 + threadIdx.x];
+    __syncthreads();
+    const size_t o = (size_t)seq * d.CAP;
+    const double fx = s.K[0], fy = s.K[4], cx = s.K[2], cy = s.K[5];
+    const double thr = (double)d.cfg.ransac_reprojection_error;
+    const float thr2 = (float)(thr * thr);
+    int cnt = 0;
+    for (int i0 = 0; i0 < s.n_tracks; i0 += 256) {
+        int i = i0 + threadIdx.x;
+        bool in = false;
+        if (i < s.n_tracks) in = point_is_inlier(Rt, fx, fy, cx, cy, d.world + 3 * (o + i), d.tl1[o + i], thr2);
+        cnt += __popcll(__ballot(in));                                // wave-level popcount of the inlier ballot
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(&total, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) d.hyp_good[(size_t)seq * d.K + h] = total;
+}
+
+// ------------------------------------------------------------------------------------------------ replay + refine + pose
+static __device__ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters) {
+    p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
+    double num = 1. - p > SVO_DBL_MIN ? 1. - p : SVO_DBL_MIN;
+    double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < SVO_DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+// Cholesky solve of a 6x6 SPD system (the damped normal equations of the LM step)
+static __device__ void chol_solve6(const double* A, const double* b, double* x) {
+    double Lm[36];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = A[6 * i + j];
+            for (int k = 0; k < j; k++) s -= Lm[6 * i + k] * Lm[6 * j + k];
+            if (i == j) Lm[6 * i + i] = sqrt(s > 1e-300 ? s : 1e-300);
+            else Lm[6 * i + j] = s / Lm[6 * j + j];
+        }
+    double y[6];
+    for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= Lm[6 * i + k] * y[k]; y[i] = s / Lm[6 * i + i]; }
+    for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= Lm[6 * k + i] * x[k]; x[i] = s / Lm[6 * i + i]; }
+}
+
+#define PF_THREADS 256
+struct LmShared {
+    double param[6], prev[6], R[9], dRdr[27], JtJ[36], JtErr[6];
+    double red[4][28];
+    double prevErrNorm;
+    int lambdaLg10, iters, state, mode;
+    int wave_tot[4]; int total;
+};
+
+// one evaluation of residuals (and Jacobians if with_J) over the inliers; totals land in sh.red[0][*]
+static __device__ void lm_eval(const DevBuffers& d, const SeqState& s, size_t o, int n, bool with_J, LmShared& sh) {
+    if (threadIdx.x == 0) rodrigues_to_matrix(sh.param, sh.R, with_J ? sh.dRdr : nullptr);
+    __syncthreads();
+    const double fx = s.K[0], fy = s.K[4], cx = s.K[2], cy = s.K[5];
+    double acc[28];
+    for (int k = 0; k < 28; k++) acc[k] = 0;
+    const double* R = sh.R; const double* dRdr = sh.dRdr;
+    const double t0 = sh.param[3], t1 = sh.param[4], t2 = sh.param[5];
+    for (int i = threadIdx.x; i < n; i += PF_THREADS) {
+        if (!d.inlier[o + i]) continue;
+        double X = d.world[3 * (o + i)], Y = d.world[3 * (o + i) + 1], Z = d.world[3 * (o + i) + 2];
+        float2 c = d.tl1[o + i];
+        double x = R[0] * X + R[1] * Y + R[2] * Z + t0;
+        double y = R[3] * X + R[4] * Y + R[5] * Z + t1;
+        double z = R[6] * X + R[7] * Y + R[8] * Z + t2;
+        z = z ? 1. / z : 1;
+        x *= z; y *= z;
+        double ex = x * fx + cx - (double)c.x, ey = y * fy + cy - (double)c.y;
+        acc[27] += ex * ex + ey * ey;
+        if (with_J) {
+            double jx[6], jy[6];
+            for (int j = 0; j < 3; j++) {
+                double dx0 = X * dRdr[9 * j + 0] + Y * dRdr[9 * j + 1] + Z * dRdr[9 * j + 2];
+                double dy0 = X * dRdr[9 * j + 3] + Y * dRdr[9 * j + 4] + Z * dRdr[9 * j + 5];
+                double dz0 = X * dRdr[9 * j + 6] + Y * dRdr[9 * j + 7] + Z * dRdr[9 * j + 8];
+                jx[j] = fx * (z * (dx0 - x * dz0));
+                jy[j] = fy * (z * (dy0 - y * dz0));
+            }
+            jx[3] = fx * z; jx[4] = 0; jx[5] = fx * (-x * z);
+            jy[3] = 0; jy[4] = fy * z; jy[5] = fy * (-y * z);
+            int q = 0;
+            for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) acc[q++] += jx[a] * jx[b] + jy[a] * jy[b];
+            for (int a = 0; a < 6; a++) acc[21 + a] += jx[a] * ex + jy[a] * ey;
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = 0; k < 28; k++) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) sh.red[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 28) sh.red[0][threadIdx.x] = sh.red[0][threadIdx.x] + sh.red[1][threadIdx.x] + sh.red[2][threadIdx.x] + sh.red[3][threadIdx.x];
+    __syncthreads();
+}
+
+static __device__ void lm_step(LmShared& sh) {
+    const double lambda = exp(sh.lambdaLg10 * log(10.));
+    double A[36], x[6];
+    for (int i = 0; i < 36; i++) A[i] = sh.JtJ[i];
+    for (int i = 0; i < 6; i++) A[7 * i] *= 1. + lambda;
+    chol_solve6(A, sh.JtErr, x);
+    for (int i = 0; i < 6; i++) sh.param[i] = sh.prev[i] - x[i];
+}
+
+__global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
+    const int seq = blockIdx.x;
+    SeqState& s = d.st[seq];
+    if (!seq_live(s)) return;
+    __shared__ LmShared sh;
+    __shared__ double bestRt[12];
+    const int n = s.n_tracks, K = d.K;
+    const size_t o = (size_t)seq * d.CAP;
+    // ---- replay of RANSACPointSetRegistrator::run's accept / shrink rule over the K precomputed inlier counts
+    if (threadIdx.x == 0) {
+        const int* good = d.hyp_good + (size_t)seq * K;
+        int niters = K > 1 ? K : 1, max_good = 0, best = -1, iters_run = 0;
+        for (int it = 0; it < niters && it < K; it++) {
+            int g = good[it];
+            iters_run = it + 1;
+            if (g > (max_good > 4 ? max_good : 4)) {
+                max_good = g; best = it;
+                niters = ransac_update_num_iters((double)d.cfg.ransac_confidence, (double)(n - g) / n, 5, niters);
+            }
+        }
+        s.pnp_best = best; s.pnp_iters = iters_run; s.pnp_good = max_good;
+        sh.total = best;
+    }
+    __syncthreads();
+    const int best = sh.total;
+    if (best < 0) { if (threadIdx.x == 0) s.fail_reason = 3; return; }        // solvePnPRansac returned false (vo.cpp:106-113)
+    if (threadIdx.x < 12) bestRt[threadIdx.x] = d.hyp[((size_t)seq * K + best) * 12 + threadIdx.x];
+    __syncthreads();
+    // ---- inlier mask of the winning hypothesis
+    {
+        const double fx = s.K[0], fy = s.K[4], cx = s.K[2], cy = s.K[5];
+        const double thr = (double)d.cfg.ransac_reprojection_error;
+        const float thr2 = (float)(thr * thr);
+        for (int i = threadIdx.x; i < n; i += PF_THREADS)
+            d.inlier[o + i] = (uint8_t)point_is_inlier(bestRt, fx, fy, cx, cy, d.world + 3 * (o + i), d.tl1[o + i], thr2);
+    }
+    __syncthreads();
+    // ---- Levenberg–Marquardt refine on the inliers (solvePnP ITERATIVE, useExtrinsicGuess; CvLevMarq state machine)
+    if (threadIdx.x == 0) {
+        double rv[3];
+        rodrigues_to_vector(bestRt, rv);
+        sh.param[0] = rv[0]; sh.param[1] = rv[1]; sh.param[2] = rv[2];
+        sh.param[3] = bestRt[9]; sh.param[4] = bestRt[10]; sh.param[5] = bestRt[11];
+        sh.lambdaLg10 = -3; sh.iters = 0; sh.state = 0; sh.mode = 1; sh.prevErrNorm = 0;
+    }
+    __syncthreads();
+    for (int guard = 0; guard < 1000; guard++) {
+        const int mode = sh.mode;
+        if (mode == 2) break;
+        lm_eval(d, s, o, n, mode == 1, sh);
+        if (threadIdx.x == 0) {
+            if (mode == 1) {                               // CALC_J: J and err at param are ready
+                int q = 0;
+                for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { sh.JtJ[6 * a + b] = sh.JtJ[6 * b + a] = sh.red[0][q++]; }
+                for (int a = 0; a < 6; a++) sh.JtErr[a] = sh.red[0][21 + a];
+                for (int a = 0; a < 6; a++) sh.prev[a] = sh.param[a];
+                lm_step(sh);
+                if (sh.iters == 0) sh.prevErrNorm = sqrt(sh.red[0][27]);
+                sh.mode = 0;
+            } else {                                       // CHECK_ERR
+                double errNorm = sqrt(sh.red[0][27]);
+                if (errNorm > sh.prevErrNorm && ++sh.lambdaLg10 <= 16) {
+                    lm_step(sh);
+                } else {
+                    sh.lambdaLg10 = sh.lambdaLg10 - 1 > -16 ? sh.lambdaLg10 - 1 : -16;
+                    double dn = 0, pn = 0;
+                    for (int a = 0; a < 6; a++) { dn += (sh.param[a] - sh.prev[a]) * (sh.param[a] - sh.prev[a]); pn += sh.prev[a] * sh.prev[a]; }
+                    if (++sh.iters >= 20 || sqrt(dn) / (sqrt(pn) + SVO_DBL_EPS) < 1.1920928955078125e-07) sh.mode = 2;
+                    else { sh.prevErrNorm = errNorm; sh.mode = 1; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- count inliers, update the feature set to the inliers at their T1 positions (vo.cpp:115-121)
+    const int fb = s.feat_buf;
+    const int chunk = (n + PF_THREADS - 1) / PF_THREADS;
+    const int i0 = threadIdx.x * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
+    int cnt = 0;
+    for (int i = i0; i < i1; i++) cnt += d.inlier[o + i];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = cnt;
+    for (int k = 1; k < 64; k <<= 1) { int t = __shfl_up(incl, k); if (lane >= k) incl += t; }
+    if (lane == 63) sh.wave_tot[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < 4; i++) { int t = sh.wave_tot[i]; sh.wave_tot[i] = acc; acc += t; } sh.total = acc; }
+    __syncthreads();
+    const int n_inl = sh.total;
+    if (threadIdx.x == 0) {
+        // success: rotation = Rodrigues(rvec), translation = tvec (vo.cpp:307-308) — before the inlier-count gate
+        rodrigues_to_matrix(sh.param, s.R, nullptr);
+        s.t[0] = sh.param[3]; s.t[1] = sh.param[4]; s.t[2] = sh.param[5];
+        s.n_inliers = n_inl;
+    }
+    if (n_inl < d.cfg.features_threshold) { if (threadIdx.x == 0) s.fail_reason = 3; return; }   // vo.cpp:106-113
+    {
+        int pos = sh.wave_tot[wv] + incl - cnt;
+        const int* fage = d.feat_age[fb] + o; const int* fstr = d.feat_str[fb] + o;
+        float2* nxy = d.feat_xy[fb ^ 1] + o; int* nage = d.feat_age[fb ^ 1] + o; int* nstr = d.feat_str[fb ^ 1] + o;
+        for (int i = i0; i < i1; i++) {
+            if (!d.inlier[o + i]) continue;
+            nxy[pos] = d.tl1[o + i]; nage[pos] = fage[i]; nstr[pos] = fstr[i];
+            d.inl_idx[o + pos] = i;
+            pos++;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s.n_feat = n_inl; s.feat_buf = fb ^ 1;
+        double rv[3];
+        double tn = sqrt(s.t[0] * s.t[0] + s.t[1] * s.t[1] + s.t[2] * s.t[2]);                 // vo.cpp:124
+        rodrigues_to_vector(s.R, rv);                                                            // vo.cpp:125
+        double angle = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);                     // vo.cpp:126
+        if (tn > d.cfg.max_translation_norm || angle > d.cfg.max_rotation_norm) { s.fail_reason = 4; return; }   // vo.cpp:129-132
+        // getInverseTransform (vo.cpp:246-258): [R t; 0 1]^-1 = [Rt, -Rt t; 0 1]
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) s.last_T[4 * i + j] = s.R[3 * j + i];
+            s.last_T[4 * i + 3] = -(s.R[i] * s.t[0] + s.R[3 + i] * s.t[1] + s.R[6 + i] * s.t[2]);
+        }
+        s.last_T[12] = s.last_T[13] = s.last_T[14] = 0; s.last_T[15] = 1;
+        s.ok = 1;
+    }
+}
+
+void launch_pnp(const DevBuffers& d, hipStream_t st) {
+    hipLaunchKernelGGL(k_pnp_subsets, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(k_pnp_epnp, dim3((d.K + 63) / 64, d.B), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(k_pnp_score, dim3(d.K, d.B), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_pnp_final, dim3(d.B), dim3(PF_THREADS), 0, st, d);
+}

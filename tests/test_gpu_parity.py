@@ -1,0 +1,358 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs.
+
+Bar: bit-exact for integer / byte / index work and for every validity mask; float point positions are
+compared bit-for-bit too (the LK arithmetic is exact-integer + IEEE f32); poses within POSE_TOL.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_T = 1e-6      # metres, per frame  (north_star states 1e-4; the implementation holds 1e-6)
+POSE_TOL_R = 1e-6      # radians, per frame
+
+
+@pytest.fixture(scope="module")
+def api():
+    from stereo_visual_odometry_amd import api as a
+    assert a._lib.device_count() >= 1, "no HIP device"
+    return a
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def rot_angle(Ra, Rb):
+    c = (np.trace(Ra.T @ Rb) - 1) / 2
+    return float(np.arccos(np.clip(c, -1, 1)))
+
+
+def images():
+    from stereo_visual_odometry_amd import synthetic as syn
+    seq = syn.StereoSequence(cal=dict(syn.KITTI00, width=640, height=200, cx=320.0, cy=100.0), n_frames=1, seed=7)
+    return {
+        "kat_featureset": scenes.featureset_scene(),
+        "texture_odd": scenes.random_texture(97, 131, 3, smooth=1),
+        "texture": scenes.random_texture(240, 320, 5, smooth=2),
+        "layers": seq.left[0],
+        "tiny": scenes.random_texture(16, 16, 9, smooth=0),
+        "black": np.zeros((64, 80), np.uint8),
+    }
+
+
+# ---------------------------------------------------------------- FAST
+@pytest.mark.parametrize("name", ["kat_featureset", "texture_odd", "texture", "layers", "tiny", "black"])
+@pytest.mark.parametrize("th", [1, 5, 20, 60])
+def test_fast_score_map_bit_exact(api, name, th):
+    img = images()[name]
+    got = api.fastScoreMap(img, th)
+    want = orc.fast_score_map(img, th)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", ["kat_featureset", "texture", "layers", "black"])
+def test_fast_detect_order_and_values(api, name):
+    img = images()[name]
+    xy, resp = api.featureDetectionFast(img, 20)
+    oxy, oresp = orc.fast_detect(img, 20)
+    assert np.array_equal(xy, oxy) and np.array_equal(resp, oresp)
+
+
+# ---------------------------------------------------------------- reference KATs against the product (main.cpp:50-172)
+def test_ref_kat_bucket(api):
+    b = api.Bucket(0)
+    for a, s in zip([6, 2, 3, 4, 5], [60, 20, 30, 40, 50]):
+        b.add_feature((1, 1), a, s)
+    assert b.max_size == 0 and b.features.size() == 0
+    b = api.Bucket(3)
+    for a, s in zip([6, 2, 3, 4, 5], [60, 20, 30, 40, 50]):
+        b.add_feature((1, 1), a, s)
+    f = b.features
+    assert f.size() == 3 and f.ages.tolist() == [6, 4, 5] and f.strengths.tolist() == [60, 40, 50]
+
+
+def test_ref_kat_featureset(api):
+    img = scenes.featureset_scene()
+    fs = api.FeatureSet()
+    fs.appendFeaturesFromImage(img, 1)
+    assert (fs.ages == 0).all() and (fs.strengths <= 128).all() and fs.size() == 11
+    fs.filterByBucketLocationInternal(img, 1, 1, 0, 7)
+    assert fs.size() == 7
+
+
+def test_ref_kat_featureset_filter(api):
+    rows = cols = 300
+    img = np.zeros((rows, cols), np.uint8)
+    fs = api.FeatureSet()
+    pts = [(cols - 1.0, rows - 1.0)] * 15 + [(cols - 1.0, 0.0)] * 10 + [(0.0, float((rows + 1) // 2))] * 5
+    fs.points = np.array(pts, np.float32); fs.ages = np.zeros(30, np.int32); fs.strengths = np.full(30, 40, np.int32)
+    fs.filterByBucketLocationInternal(img, 2, 2, 0, 11)
+    assert fs.size() == 26
+    cp = api.FeatureSet(); cp.points, cp.ages, cp.strengths = fs.points.copy(), fs.ages.copy(), fs.strengths.copy()
+    fs.filterByBucketLocationInternal(img, 2, 1, 0, 11)
+    assert fs.size() == 21
+    cp.filterByBucketLocationInternal(img, 1, 2, 0, 11)
+    assert cp.size() == 16
+
+
+def test_ref_kat_find_unmoved_points(api):
+    p1 = np.array([(i, i) for i in range(35)], np.float32)
+    p2 = np.array([(i + (0 if i % 5 else 1), i + (0 if i % 7 else 1)) for i in range(35)], np.float32)
+    ok = api.findClosePoints(p1, p2, 0.5)
+    assert ok.tolist() == [bool((i % 5) and (i % 7)) for i in range(35)]
+
+
+# ---------------------------------------------------------------- bucketing parity
+@pytest.mark.parametrize("per_bucket,grid", [(1, (92, 160, 4)), (3, (10, 12, 1)), (7, (1, 1, 0)), (2, (5, 9, 2))])
+def test_bucket_filter_parity(api, per_bucket, grid):
+    rng = np.random.default_rng(11 + per_bucket)
+    n, w, h = 3000, 640, 360
+    xy = np.stack([rng.uniform(0, w - 0.01, n), rng.uniform(0, h - 0.01, n)], 1).astype(np.float32)
+    xy[::3] = np.floor(xy[::3])
+    ages = rng.integers(0, 25, n).astype(np.int32)
+    st = rng.integers(0, 200, n).astype(np.int32)
+    want = orc.bucket_filter(w, h, xy, ages, st, grid[0], grid[1], grid[2], per_bucket)
+    fs = api.FeatureSet(); fs.points, fs.ages, fs.strengths = xy.copy(), ages.copy(), st.copy()
+    fs.filterByBucketLocationInternal(np.zeros((h, w), np.uint8), grid[0], grid[1], grid[2], per_bucket)
+    assert np.array_equal(bits(fs.points), bits(want[0])) and np.array_equal(fs.ages, want[1]) and np.array_equal(fs.strengths, want[2])
+
+
+@pytest.mark.parametrize("name,th", [("texture", 20), ("layers", 20), ("layers", 5), ("black", 20)])
+def test_append_features_fused_parity(api, name, th):
+    """FAST -> atomicMax bucket keys -> raster emit must equal cv::FAST order + sequential Bucket::add_feature."""
+    img = images()[name]
+    h, w = img.shape
+    rng = np.random.default_rng(5)
+    n0 = 400
+    oxy = np.stack([rng.uniform(0, w - 0.01, n0), rng.uniform(0, h - 0.01, n0)], 1).astype(np.float32)
+    oag = rng.integers(0, 24, n0).astype(np.int32)
+    ost = rng.integers(5, 250, n0).astype(np.int32)
+    xy, resp = orc.fast_detect(img, th)
+    want = orc.bucket_filter(w, h, np.concatenate([oxy, xy]), np.concatenate([oag, np.zeros(len(xy), np.int32)]),
+                             np.concatenate([ost, resp.astype(np.int32)]))
+    fs = api.FeatureSet(); fs.points, fs.ages, fs.strengths = oxy.copy(), oag.copy(), ost.copy()
+    fs.appendFeaturesFromImage(img, th)
+    assert fs.size() == len(want[1])
+    assert np.array_equal(bits(fs.points), bits(want[0])) and np.array_equal(fs.ages, want[1]) and np.array_equal(fs.strengths, want[2])
+
+
+# ---------------------------------------------------------------- pyramid
+@pytest.mark.parametrize("name,win,lv", [("texture", 10, 3), ("texture_odd", 10, 3), ("layers", 21, 3), ("layers", 21, 4), ("tiny", 7, 3)])
+def test_pyramid_bit_exact(api, name, win, lv):
+    img = images()[name]
+    got = api.buildOpticalFlowPyramid(img, win, lv)
+    want = orc.Pyramid(img, (win, win), lv)
+    assert len(got) == want.nlevels
+    for l in range(want.nlevels):
+        assert np.array_equal(got[l], want.level(l)), "level %d" % l
+
+
+# ---------------------------------------------------------------- LK
+def lk_points(w, h, n, seed):
+    rng = np.random.default_rng(seed)
+    p = np.stack([rng.uniform(-3, w + 3, n), rng.uniform(-3, h + 3, n)], 1).astype(np.float32)
+    p[: n // 4] = np.floor(p[: n // 4])
+    p[0] = (0, 0); p[1] = (w - 1, h - 1); p[2] = (-20, 5); p[3] = (w + 30, h + 30); p[4] = (0.5, h - 0.5)
+    return p
+
+
+@pytest.mark.parametrize("win,lv", [(10, 3), (21, 3), (21, 4), (7, 2), (15, 3), (31, 2)])
+@pytest.mark.parametrize("shift", [(1, 0), (4, -3), (13, 2)])
+def test_lk_track_bit_exact(api, win, lv, shift):
+    a = scenes.random_texture(200, 320, 21, smooth=2)
+    b = scenes.shift_image(a, *shift)
+    b = np.clip(b.astype(np.int32) + np.random.default_rng(1).integers(-2, 3, b.shape), 0, 255).astype(np.uint8)
+    pts = lk_points(320, 200, 300, 17)
+    got, gst = api.calcOpticalFlowPyrLK(a, b, pts, win, lv)
+    pa, pb = orc.Pyramid(a, (win, win), lv), orc.Pyramid(b, (win, win), lv)
+    want, wst = orc.lk_track(pa, pb, pts, (win, win), lv)
+    assert np.array_equal(gst, wst)
+    assert np.array_equal(bits(got), bits(want))
+    assert wst.sum() > 100        # the case is not vacuous
+
+
+def test_lk_flat_image_fails_min_eig(api):
+    a = np.full((100, 120), 77, np.uint8)
+    pts = lk_points(120, 100, 40, 3)
+    got, gst = api.calcOpticalFlowPyrLK(a, a, pts, 10, 3)
+    pa = orc.Pyramid(a, (10, 10), 3)
+    want, wst = orc.lk_track(pa, pa, pts, (10, 10), 3)
+    assert np.array_equal(gst, wst) and np.array_equal(bits(got), bits(want)) and gst.sum() == 0
+
+
+def test_ref_kat_circular_matching(api):                   # main.cpp:174-209
+    iL0, iR0, iL1, iR1 = scenes.circular_scene()
+    cfg = api.default_config()
+    fs = api.FeatureSet()
+    fs.appendFeaturesFromImage(iL0, api.FAST_THRESHOLD)
+    assert fs.size() == 121
+    pl1, pr1, pr0, plc, ok = api.circularMatching(cfg, iL0, iR0, iL1, iR1, fs.points)
+    assert ok.sum() == 121
+    pl1b, pr1b, pr0b, plcb, okb = api.circularMatching(cfg, iL1, iR1, iL1, iR1, fs.points)   # what the reference test really runs
+    assert okb.sum() == 121
+    api.circularMatching(cfg, iL0, iR0, iL1, iR1, np.zeros((0, 2), np.float32))              # boundary conditions
+    assert api.circularMatching(cfg, iL0, iR0, iL1, iR1, fs.points[:1])[4].tolist() == [1]
+    # and bit-exact against the oracle
+    ocfg = orc.default_config()
+    P = [orc.Pyramid(i, (10, 10), 3) for i in (iL0, iR0, iL1, iR1)]
+    w = orc.circular_match(P[0], P[1], P[2], P[3], fs.points, ocfg)
+    for g, o in zip((pl1, pr1, pr0, plc), w[:4]):
+        assert np.array_equal(bits(g), bits(o))
+    assert np.array_equal(ok, w[4])
+
+
+@pytest.mark.parametrize("win", [10, 21])
+def test_circular_match_parity_stereo_scene(api, win):
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=480, height=200, cx=240.0, cy=100.0)
+    seq = syn.StereoSequence(cal=cal, n_frames=2, seed=3)
+    cfg = api.default_config(win_w=win, win_h=win)
+    ocfg = orc.default_config(win_w=win, win_h=win)
+    xy, resp = orc.fast_detect(seq.left[0], 20)
+    fxy, _, _ = orc.bucket_filter(480, 200, xy, np.zeros(len(xy), np.int32), resp.astype(np.int32))
+    got = api.circularMatching(cfg, seq.left[0], seq.right[0], seq.left[1], seq.right[1], fxy)
+    P = [orc.Pyramid(i, (win, win), 3) for i in (seq.left[0], seq.right[0], seq.left[1], seq.right[1])]
+    want = orc.circular_match(P[0], P[1], P[2], P[3], fxy, ocfg)
+    assert np.array_equal(got[4], want[4])
+    for g, o in zip(got[:4], want[:4]):
+        assert np.array_equal(bits(g), bits(o))
+    assert 0.3 * len(fxy) < want[4].sum() < len(fxy)       # both outcomes occur
+
+
+# ---------------------------------------------------------------- triangulation / PnP
+def test_triangulate_bit_exact_and_analytic(api):
+    from stereo_visual_odometry_amd import synthetic as syn
+    Pl, Pr = syn.projection_matrices(syn.KITTI00)
+    rng = np.random.default_rng(2)
+    n = 2000
+    Z = rng.uniform(4, 90, n); X = rng.uniform(-20, 20, n); Y = rng.uniform(-3, 3, n)
+    ul = 718.856 * X / Z + 607.1928; v = 718.856 * Y / Z + 185.2157; ur = ul - 386.1448 / Z
+    pl = np.stack([ul, v], 1).astype(np.float32); pr = np.stack([ur, v + rng.normal(0, 0.05, n)], 1).astype(np.float32)
+    got = api.triangulatePoints(Pl, Pr, pl, pr)
+    want, _ = orc.triangulate(Pl, Pr, pl, pr)
+    assert np.array_equal(bits(got), bits(want))
+    # analytic pin (no reference test covers cv::triangulatePoints): Z = -bf / (xl - xr) when yl == yr
+    pr2 = np.stack([ur, v], 1).astype(np.float32)
+    z = api.triangulatePoints(Pl, Pr, pl, pr2)[:, 2]
+    zz = 386.1448 / (pl[:, 0].astype(np.float64) - pr2[:, 0].astype(np.float64))
+    assert np.abs(z / zz - 1).max() < 1e-4
+
+
+def test_ref_kat_camera_to_world(api):                      # main.cpp:211-264
+    K, cam, world = scenes.camera_to_world_scene()
+    (inl, ok), R, t, iters = api.cameraToWorld(K, cam, world, np.eye(3), np.zeros(3))
+    assert ok and len(inl) == 27 and inl.tolist() == list(range(27))
+    t = t.ravel()
+    assert abs(t[0]) < 1e-6 and abs(t[1]) < 1e-6 and abs(t[2] - 1) < 1e-6
+    assert np.abs(R - np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]])).max() < 1e-8
+
+
+@pytest.mark.parametrize("outliers,iters", [(0.0, 100), (0.3, 100), (0.6, 300)])
+def test_camera_to_world_parity(api, outliers, iters):
+    rng = np.random.default_rng(int(outliers * 10) + 1)
+    n = 800
+    K = np.array([[718.856, 0, 607.1928], [0, 718.856, 185.2157], [0, 0, 1]], np.float32)
+    world = np.stack([rng.uniform(-15, 15, n), rng.uniform(-3, 3, n), rng.uniform(6, 60, n)], 1).astype(np.float32)
+    rv = np.array([0.01, -0.02, 0.005]); tv = np.array([0.05, -0.02, -0.6])
+    Rm, _ = orc.rodrigues_to_matrix(rv)
+    pc = world.astype(np.float64) @ Rm.T + tv
+    cam = np.stack([718.856 * pc[:, 0] / pc[:, 2] + 607.1928, 718.856 * pc[:, 1] / pc[:, 2] + 185.2157], 1)
+    cam += rng.normal(0, 0.2, cam.shape)
+    bad = rng.random(n) < outliers
+    cam[bad] += rng.uniform(-80, 80, (bad.sum(), 2))
+    cam = cam.astype(np.float32)
+    ok_o, R_o, t_o, inl_o, dbg = orc.camera_to_world(K, cam, world, np.eye(3), np.zeros(3), iters)
+    (inl, ok), R, t, it = api.cameraToWorld(K, cam, world, np.eye(3), np.zeros(3), iterations=iters)
+    assert ok == ok_o and it == dbg[0]
+    assert np.array_equal(inl, inl_o)                       # inlier mask bit-exact
+    assert np.abs(t.ravel() - t_o).max() < POSE_TOL_T and rot_angle(R, R_o) < POSE_TOL_R
+    assert np.abs(t.ravel() - tv).max() < 0.05              # and it is the right pose
+
+
+# ---------------------------------------------------------------- whole frames
+def run_both(api, seq, cfg_over, n_frames):
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = seq.cal
+    Pl, Pr = syn.projection_matrices(cal)
+    ovo = orc.VisualOdometry(orc.default_config(**cfg_over)); ovo.initalize_projection_matricies(Pl, Pr)
+    gvo = api.VisualOdometry(cfg=api.default_config(**cfg_over)); gvo.initalize_projection_matricies(Pl, Pr)
+    out = []
+    for k in range(n_frames):
+        ok_o, T_o = ovo.stereo_callback(seq.left[k], seq.right[k])
+        ok_g, T_g = gvo.stereo_callback(seq.left[k], seq.right[k])
+        so = {f[0]: getattr(ovo.stats, f[0]) for f in ovo.stats._fields_}
+        sg = gvo.stats.as_dict()
+        assert ok_o == ok_g, (k, so, sg)
+        assert so == sg, (k, so, sg)
+        fo, fg = ovo.features(), gvo.features()
+        assert np.array_equal(bits(fo[0]), bits(fg[0])) and np.array_equal(fo[1], fg[1]) and np.array_equal(fo[2], fg[2]), k
+        if k > 0:
+            to, tg = ovo.last_tracks(), gvo.last_tracks()
+            for key in ("pl0", "pr0", "pl1", "pr1"):
+                assert np.array_equal(bits(to[key]), bits(tg[key])), (k, key)
+            if so["fail_reason"] in (0, 3, 4) and so["n_after_bounds"] > 15:
+                assert np.array_equal(bits(to["world"]), bits(tg["world"])), k
+                assert np.array_equal(to["inlier"], tg["inlier"]), k
+        assert np.abs(T_o[:3, 3] - T_g[:3, 3]).max() < POSE_TOL_T, (k, T_o, T_g)
+        assert rot_angle(T_o[:3, :3], T_g[:3, :3]) < POSE_TOL_R, k
+        out.append((ok_g, T_g, sg))
+    return out
+
+
+@pytest.mark.parametrize("win,lv", [(10, 3), (21, 3)])
+def test_stereo_callback_sequence_parity(api, win, lv):
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=480, height=200, cx=240.0, cy=100.0)
+    seq = syn.StereoSequence(cal=cal, n_frames=5, seed=12, step=0.4)
+    res = run_both(api, seq, dict(win_w=win, win_h=win, max_level=lv, max_translation_norm=2.0), 5)
+    assert res[0][0] is False and res[0][2]["fail_reason"] == 1
+    assert all(r[0] for r in res[1:])
+    gt = seq.relative_motion(2)
+    assert np.abs(res[2][1][:3, 3] - gt[:3, 3]).max() < 0.03
+
+
+def test_stereo_callback_failure_paths_parity(api):
+    """too-few-tracks (black frames -> second FAST pass, empty feature set, stale pyramid quirk), then recovery,
+    then the motion gate (reference default MAX_TRANSLATION_NORM with a 0.4 m step)."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=480, height=200, cx=240.0, cy=100.0)
+    seq = syn.StereoSequence(cal=cal, n_frames=4, seed=5, step=0.4)
+    black = np.zeros_like(seq.left[0])
+    seq.left = [black, black] + seq.left
+    seq.right = [black, black] + seq.right
+    res = run_both(api, seq, dict(), 6)
+    reasons = [r[2]["fail_reason"] for r in res]
+    assert reasons[0] == 1 and reasons[1] == 2 and reasons[2] == 2
+    assert res[1][2]["second_pass"] == 1
+    assert 4 in reasons[3:]                                  # the 0.1 m gate rejects the 0.4 m steps
+
+
+def test_kitti_shaped_frame_parity(api):
+    """full BASELINE cfg2 size (1241x376, 21x21 window, 3 levels), two frames."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    seq = syn.StereoSequence(n_frames=3, seed=0x5EED0002)
+    res = run_both(api, seq, dict(win_w=21, win_h=21, max_level=3, max_translation_norm=2.0), 3)
+    assert res[1][0] and res[2][0] and res[2][2]["n_inliers"] > 500
+
+
+def test_batch_equals_single(api):
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=480, height=200, cx=240.0, cy=100.0)
+    seqs = [syn.StereoSequence(cal=cal, n_frames=3, seed=s, step=0.3) for s in (1, 2, 3)]
+    Pl, Pr = syn.projection_matrices(cal)
+    cfg = api.default_config(win_w=21, win_h=21, max_translation_norm=2.0)
+    singles = []
+    for s in seqs:
+        vo = api.VisualOdometry(cfg=cfg); vo.initalize_projection_matricies(Pl, Pr)
+        singles.append([vo.stereo_callback(s.left[k], s.right[k]) + (vo.stats.as_dict(),) for k in range(3)])
+    b = api.BatchVisualOdometry(480, 200, 3, cfg); b.initalize_projection_matricies(Pl, Pr)
+    for k in range(3):
+        ok, T = b.stereo_callback_batch([s.left[k] for s in seqs], [s.right[k] for s in seqs])
+        for i in range(3):
+            assert ok[i] == singles[i][k][0]
+            assert np.array_equal(T[i], singles[i][k][1])           # same kernels, same order: identical bits
+            assert b.stats[i].as_dict() == singles[i][k][2]
