@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — stereo frame-pairs/s of the HIP front end on KITTI-00-shaped synthetic input.
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU.  A step = one frame pair for each of the --seqs
+sequences resident on a GPU (inputs already in HBM).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
+
+
+def level_sizes(W, H, win, max_level):
+    out = []
+    w, h = W, H
+    for l in range(max_level + 1):
+        out.append(w * h)
+        w, h = (w + 1) // 2, (h + 1) // 2
+        if w <= win or h <= win:
+            break
+    return out
+
+
+def algorithmic_bytes(W, H, N, win, max_level, K, r=4):
+    """SURVEY.md §8(d) / BASELINE.md §4 byte model per frame pair -> (total, lk_chain_only)."""
+    px = level_sizes(W, H, win, max_level)
+    L = len(px) - 1
+    ingest = 2 * px[0]
+    pyr = 2 * (sum(px[:L]) + sum(px[1:]))
+    fast = px[0] + 16 * N
+    lk = 4 * (sum(min(N * ((win + 3) ** 2 + (win + 1 + 2 * r) ** 2), 2 * p) for p in px) + 17 * N)
+    geo = 49 * N + 48 * K
+    return ingest + pyr + fast + lk + geo, lk
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--seqs", type=int, default=32, help="independent stereo sequences batched per GPU")
+    ap.add_argument("--depth", type=int, default=4, help="frames kept in flight per GPU (<= 8)")
+    ap.add_argument("--pool", type=int, default=2, help="distinct synthetic sequences rendered per rank")
+    ap.add_argument("--frames", type=int, default=10, help="frames rendered per pool sequence (ping-pong replay)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from stereo_visual_odometry_amd import api, sharding, synthetic as syn
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- workload: BASELINE.json configs[1] — KITTI-00 shaped 1241x376, ~2000 FAST features, LK 21x21, maxLevel 3
+    cal = syn.KITTI00
+    W, H = cal["width"], cal["height"]
+    over = dict(win_w=21, win_h=21, max_level=3, ransac_iterations=100, max_translation_norm=2.0)
+    B, F = args.seqs, args.frames
+    pool = [syn.StereoSequence(cal=cal, n_frames=F, seed=0x5EED0002 + 97 * rank + g, step=0.5, cell_px=17.6)
+            for g in range(args.pool)]
+    left = torch.stack([torch.from_numpy(np.stack(s.left)) for s in pool]).to(dev)      # (G, F, H, W) u8, resident in HBM
+    right = torch.stack([torch.from_numpy(np.stack(s.right)) for s in pool]).to(dev)
+    frame_bytes = W * H
+
+    def ping_pong(i):
+        p = i % (2 * F - 2)
+        return p if p < F else 2 * F - 2 - p
+
+    def ptrs(step):
+        lp, rp = [], []
+        for b in range(B):
+            g = b % args.pool
+            f = ping_pong(step + (b // args.pool) * 3)       # phase offsets: every slot sees a different frame stream
+            lp.append(left.data_ptr() + (g * F + f) * frame_bytes)
+            rp.append(right.data_ptr() + (g * F + f) * frame_bytes)
+        return lp, rp
+
+    vo = api.BatchVisualOdometry(W, H, B, api.default_config(**over), device=local_rank)
+    Pl, Pr = syn.projection_matrices(cal)
+    vo.initalize_projection_matricies(Pl, Pr)
+
+    total = args.warmup + args.steps
+    depth = max(1, min(args.depth, 8))
+    poses = np.zeros((B, args.steps, 17))
+    n_lk, n_ok, lk_ms, fr_ms = [], 0, [], []
+
+    def run(first, count, record):
+        nonlocal n_ok
+        sub = col = 0
+        while col < count:
+            while sub < count and sub - col < depth:
+                lp, rp = ptrs(first + sub)
+                vo.submit_device(lp, rp, W)
+                sub += 1
+            ok, T = vo.collect()
+            if record:
+                a, b = vo.last_timing()                      # HIP events on the context's own stream
+                lk_ms.append(a); fr_ms.append(b)
+                n_lk.append(np.mean([s.n_into_lk for s in vo.stats]))
+                n_ok += int(ok.sum())
+                poses[:, col, :16] = T.reshape(B, 16); poses[:, col, 16] = ok
+            col += 1
+
+    run(0, args.warmup + 1, False)                           # frame 0 only primes the pipeline (vo.cpp:47-56), then W warm-up steps
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run(args.warmup + 1, args.steps, True)
+    if world > 1:                                            # the path's only exchange: pose streams -> rank 0 (RCCL over xGMI)
+        gathered = sharding.gather_pose_streams(torch.from_numpy(poses).to(dev), dst=0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        okt = torch.tensor([n_ok], dtype=torch.float64, device=dev)
+        dist.all_reduce(okt)
+        n_ok_all = int(okt.item())
+    else:
+        n_ok_all = n_ok
+
+    if rank == 0:
+        N = float(np.mean(n_lk))
+        bytes_total, bytes_lk = algorithmic_bytes(W, H, N, 21, 3, 100)
+        lk_avg_ms = float(np.mean(lk_ms))
+        achieved = bytes_lk * B / (lk_avg_ms * 1e-3) / 1e9     # algorithmic GB/s of the dominant kernel (k_lk_chain)
+        value = world * B * args.steps / dt
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_lk_chain_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        cpu = None
+        if world == 1 and args.cpu_frames > 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as orc
+            o = orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl, Pr)
+            s = pool[0]
+            o.stereo_callback(s.left[0], s.right[0])
+            c0 = time.perf_counter()
+            for i in range(1, args.cpu_frames + 1):
+                f = ping_pong(i)
+                o.stereo_callback(s.left[f], s.right[f])
+            cdt = time.perf_counter() - c0
+            cpu = {"value": args.cpu_frames / cdt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+                   "sample": "%d frame pairs of the same 1241x376 synthetic sequence through oracle/ (plain C, -O2, 1 thread)" % args.cpu_frames}
+        out = {
+            "metric": "stereo frame-pairs/sec on KITTI-00 1241x376 @2k feats", "value": value, "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int64/f32 (LK), f64 (PnP)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: KITTI-00 calibration, 1241x376, LK 21x21 win, maxLevel 3, 100 RANSAC-PnP iterations",
+                       "sequences_per_gpu": B, "frames_in_flight": depth, "mean_features_into_lk": N,
+                       "pose_ok_fraction": n_ok_all / float(world * B * args.steps)},
+            "roofline": {"bound": "hbm", "kernel": "k_lk_chain<21>", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_frame_pair": {"lk_chain": bytes_lk, "whole_frame": bytes_total},
+                         "kernel_avg_ms": lk_avg_ms, "frame_avg_ms": float(np.mean(fr_ms)),
+                         "whole_frame_frac": bytes_total * value / world / 1e9 / PEAK_HBM_GBS},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
