@@ -1,0 +1,98 @@
+// The reference's run_tests() (src/main.cpp:50-264, 293-312) restated against the C++ facade
+// include/svo/visual_odometry.hpp — the same calls a maintainer's main.cpp would make, with the OpenCV
+// types substituted.  Exits 0 when every known answer holds.  Needs an MI355X (everything runs in HIP).
+#include <cassert>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "svo/visual_odometry.hpp"
+using namespace visual_odometry;
+
+#define CHECK(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); std::exit(1); } } while (0)
+
+struct Img {                                   // makeEmptyImage (main.cpp:80-88)
+    int rows, cols; std::vector<uint8_t> px;
+    Img(int r, int c) : rows(r), cols(c), px((size_t)r * c, 0) {}
+    uint8_t& at(int y, int x) { return px[(size_t)y * cols + x]; }
+    Image view() const { return Image(px.data(), rows, cols); }
+};
+static void addTriangle(Img& image, int x, int y, int r) {          // main.cpp:89-100
+    for (int i = -r; i <= r; i++)
+        for (int j = 0; j <= r; j++)
+            if (std::abs(i) <= r - std::abs(j)) image.at(i + y, j + x) = 120;
+    image.at(y, x) = 0;
+}
+
+static void test_bucket() {                                         // main.cpp:50-78
+    int ages[] = {6, 2, 3, 4, 5}, strengths[] = {60, 20, 30, 40, 50};
+    Bucket e(0);
+    for (int i = 0; i < 5; i++) e.add_feature(Point2f{1, 1}, ages[i], strengths[i]);
+    CHECK(e.max_size == 0 && e.features.size() == 0);
+    Bucket b(3);
+    for (int i = 0; i < 5; i++) b.add_feature(Point2f{1, 1}, ages[i], strengths[i]);
+    CHECK(b.features.size() == 3);
+    CHECK(b.features.ages[0] == 6 && b.features.ages[1] == 4 && b.features.ages[2] == 5);
+    CHECK(b.features.strengths[0] == 60 && b.features.strengths[1] == 40 && b.features.strengths[2] == 50);
+}
+
+static void test_featureset() {                                     // main.cpp:102-127
+    FeatureSet fs;
+    Img im(300, 200);
+    for (int i = 0; i <= 10; i++) addTriangle(im, 20, (i + 1) * 20, 8);
+    fs.appendFeaturesFromImage(im.view(), 1);
+    for (int a : fs.ages) CHECK(a == 0);
+    for (int s : fs.strengths) CHECK(s <= 128);
+    CHECK(fs.size() == 11);
+    fs.filterByBucketLocationInternal(im.view(), 1, 1, 0, 7);
+    CHECK(fs.size() == 7);
+}
+
+static void test_findUnmovedPoints() {                              // main.cpp:161-172
+    std::vector<Point2f> p1, p2;
+    for (int i = 0; i < 35; i++) { p1.push_back({float(i), float(i)}); p2.push_back({float(i) + !(i % 5), float(i) + !(i % 7)}); }
+    std::vector<bool> ok = findClosePoints(p1, p2, .5f);
+    for (int i = 0; i < 35; i++) CHECK(ok[i] == ((i % 5) && (i % 7)));
+}
+
+static void test_cameraToWorld() {                                  // main.cpp:211-264
+    Mat33f K = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::vector<Point3f> world; std::vector<Point2f> cam;
+    for (int i = -1; i <= 1; i++) for (int j = -1; j <= 1; j++) for (int k = 5; k <= 7; k++) {
+        world.push_back({float(-j), float(i), float(k)});
+        cam.push_back({float(i) / (k + 1), float(j) / (k + 1)});
+    }
+    Mat33d R = {1, 0, 0, 0, 1, 0, 0, 0, 1}; Vec3d t = {0, 0, 0};
+    auto result = cameraToWorld(K, cam, world, R, t);
+    CHECK(std::fabs(t[0]) < 1e-6 && std::fabs(t[1]) < 1e-6 && std::fabs(t[2] - 1) < 1e-6);
+    const double want[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+    for (int i = 0; i < 9; i++) CHECK(std::fabs(R[i] - want[i]) < 1e-8);
+    CHECK(result.second && (int)result.first.size() == 27);
+}
+
+static void test_stereo_callback_shape() {                          // the callback contract of vo.h:318-334
+    Img l0(600, 600), r0(600, 600), l1(600, 600), r1(600, 600);
+    for (int i = 0; i <= 10; i++) for (int j = 0; j <= 10; j++) {
+        addTriangle(l0, (j + 1) * 40, (i + 1) * 40, 8); addTriangle(l1, (j + 1) * 40 + 1, (i + 1) * 40, 8);
+        addTriangle(r0, (j + 1) * 40, (i + 1) * 40 + 1, 8); addTriangle(r1, (j + 1) * 40 + 1, (i + 1) * 40 + 1, 8);
+    }
+    VisualOdometry vo;
+    Mat34f Pl = {322.11376f, 0, 327.47336f, 0, 0, 322.11376f, 176.33722f, 0, 0, 0, 1, 0};   // main.cpp:357-362
+    Mat34f Pr = Pl; Pr[3] = -22.5428f;
+    vo.initalize_projection_matricies(Pl, Pr);
+    auto a = vo.stereo_callback(l0.view(), r0.view());
+    CHECK(a.first == false);                                        // first frame never yields a pose (vo.cpp:47-56)
+    for (int i = 0; i < 16; i++) CHECK(a.second[i] == (i % 5 == 0 ? 1.0 : 0.0));
+    auto b = vo.stereo_callback(l1.view(), r1.view());
+    CHECK(vo.stats.n_after_circular == 121);                        // test_circularMatching's count (main.cpp:208)
+    (void)b;
+}
+
+int main() {
+    std::puts("TEST BUCKET"); test_bucket();
+    std::puts("TEST FEATURE SET"); test_featureset();
+    std::puts("TEST FIND UNMOVED POINTS"); test_findUnmovedPoints();
+    std::puts("TEST CAMERA TO WORLD"); test_cameraToWorld();
+    std::puts("TEST STEREO CALLBACK"); test_stereo_callback_shape();
+    std::puts("ALL TESTS PASS");
+    return 0;
+}

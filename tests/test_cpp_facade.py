@@ -1,0 +1,30 @@
+"""The C++ facade (include/svo/visual_odometry.hpp) compiles with plain g++ against the C-ABI, and on a GPU
+the reference's run_tests() restated with it (tests/cpp/facade_kat.cpp) passes."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "facade_kat.cpp")
+EXE = os.path.join(ROOT, "tests", "cpp", "facade_kat")
+
+
+def build():
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), SRC, "-o", EXE,
+           "-L" + os.path.join(ROOT, "stereo_visual_odometry_amd"), "-lsvo_hip",
+           "-Wl,-rpath," + os.path.join(ROOT, "stereo_visual_odometry_amd")]
+    subprocess.check_call(cmd)
+
+
+def test_facade_compiles_and_links_with_gxx():
+    build()
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_reference_run_tests_through_facade():
+    build()
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ALL TESTS PASS" in out.stdout
