@@ -112,6 +112,9 @@ void orc_pyramid_free(orc_pyramid* p) {
     p->nlevels = 0;
 }
 
+/* debug counters (test infrastructure): [0] level visits that reached the Newton loop, [1] Newton iterations, [2] level visits total */
+long long orc_lk_counters[4] = {0, 0, 0, 0};
+
 #define W_BITS 14
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
@@ -140,6 +143,7 @@ static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int 
         else { npx = next_pts[2 * i] * 2.f; npy = next_pts[2 * i + 1] * 2.f; }
         next_pts[2 * i] = npx; next_pts[2 * i + 1] = npy;
 
+        orc_lk_counters[2]++;
         ppx -= half_x; ppy -= half_y;
         int ipx = cv_floor_f(ppx), ipy = cv_floor_f(ppy);
         if (ipx < -ww || ipx >= colsI || ipy < -wh || ipy >= rowsI) {
@@ -174,6 +178,7 @@ static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int 
             continue;
         }
         D = 1.f / D;
+        orc_lk_counters[0]++;
         npx -= half_x; npy -= half_y;
         float pdx = 0.f, pdy = 0.f;
         for (j = 0; j < max_count; j++) {
@@ -182,6 +187,7 @@ static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int 
                 if (level == 0) status[i] = 0;
                 break;
             }
+            orc_lk_counters[1]++;
             a = npx - inx; b = npy - iny;
             iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
             iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));

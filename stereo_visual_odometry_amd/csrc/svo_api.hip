@@ -117,7 +117,7 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     int rc;
 #define ALLOC(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != SVO_OK) return rc;
     ALLOC(d.st, B);
-    ALLOC(d.pyr, B * 6 * (size_t)d.geom.pyr_bytes);
+    ALLOC(d.pyr, B * 6 * (size_t)d.geom.pyr_bytes + 256);        // + slack: the LK kernel's unaligned dword loads may read a few bytes past a row
     for (int k = 0; k < 2; k++) { ALLOC(d.feat_xy[k], B * CAP); ALLOC(d.feat_age[k], B * CAP); ALLOC(d.feat_str[k], B * CAP); }
     ALLOC(d.bucket_keys, B * (size_t)d.NB);
     ALLOC(d.pl0, B * CAP); ALLOC(d.pl1, B * CAP); ALLOC(d.pr1, B * CAP); ALLOC(d.pr0, B * CAP); ALLOC(d.plc, B * CAP);

@@ -3,22 +3,27 @@
 // Replaces cv::calcOpticalFlowPyrLK as called four times by VisualOdometry::circularMatching
 // (reference src/vo.cpp:203-215) and the status / loop-closure / in-bounds masks (vo.cpp:217-230,
 // 341-359).  The four passes L0->L1->R1->R0->L0 of one feature are independent of every other
-// feature, so ONE launch runs the whole chain: one single-wave workgroup per feature, all pyramid
-// levels and all Newton iterations inside it.
+// feature, so ONE launch runs the whole chain: one single-wave workgroup walks features, and for each
+// runs all pyramid levels and all Newton iterations of all four passes.
 //
-// MI355X mapping (no MFMA: there is no dense contraction here):
-//   * the (w+3)^2 source tile of the template image is staged once per level into LDS; Scharr
-//     derivatives are computed from it on the fly — no derivative pyramid ever exists in HBM;
-//   * each lane owns PPL consecutive pixels of one window row, and keeps their I, Ix, Iy samples in
-//     VGPRs for the whole Newton loop;
-//   * the search-image window is staged as an LDS tile with a +-LK_M px guard band and only
-//     re-staged when the window walks out of it;
-//   * the 2x2 normal matrix and the mismatch vector are per-lane int32 partials reduced across the
-//     wave with shuffles as exact int64 — order-independent, so the result is bit-identical to the
-//     sequential CPU loop; the float tail runs identically on every lane.
+// MI355X mapping (no MFMA: there is no dense contraction here).  Round-1 profiling of a first version
+// that staged tiles in LDS and reduced with __shfl_xor showed the kernel LDS-issue-bound
+// (SQ_WAIT_INST_LDS = 53 % of wave cycles; 64-bit shuffles lower to ds_bpermute and byte-granular
+// ds_read_u8 traffic saturated the LDS pipe).  This version keeps everything in registers:
+//   * each lane owns PPL consecutive pixels of one window row; it loads the 4 x (PPL+3) source bytes
+//     it needs straight from the (L2 / Infinity-Cache resident) pyramid with unaligned dword loads,
+//     computes the Scharr derivatives in registers (no derivative pyramid in HBM, no LDS tile) and
+//     keeps I, Ix, Iy of its pixels in VGPRs for the whole Newton loop;
+//   * the search-image window (2 rows x (PPL+1) bytes per lane) is also held in VGPRs and only
+//     re-loaded when the INTEGER window position changes — in the sub-pixel phase of the Newton
+//     iteration (most steps) the loop touches no memory at all;
+//   * windows that cross the image border take a per-byte REFLECT_101 path (rare);
+//   * the 2x2 normal matrix and the mismatch vector are per-lane int32 partials, split into 16-bit
+//     halves and reduced with DPP row operations + v_readlane into SGPRs — exact integers, so the
+//     result is order-independent and bit-identical to the sequential CPU loop, and the float tail
+//     and every branch are wave-uniform.
 #include "svo_internal.hpp"
 
-#define LK_M 4                                   // guard band of the search tile (pixels)
 #define LK_WBITS 14
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
@@ -35,19 +40,26 @@ template <int W> struct LkLayout {
     }
     static constexpr int PPL = ppl();
     static constexpr int LPR = (W + PPL - 1) / PPL;   // lanes per window row
-    static constexpr int SW = W + 3;                  // template source tile side
-    static constexpr int DW = W + 1;                  // derivative tile side
-    static constexpr int TS = W + 1 + 2 * LK_M;       // search tile side
+    static constexpr int EXT = LPR * PPL;             // columns covered by the lanes of a row (>= W)
+    static constexpr int NS = PPL + 3;                // template source bytes per lane per row
+    static constexpr int NB = PPL + 1;                // search-window bytes per lane per row
 };
 
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ int dpp_row_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+    return v;
+}
+// exact wave-wide sum of int32 partials as int64, returned in SGPRs (uniform)
 __device__ __forceinline__ long long wave_sum_i64(int partial) {
-    long long v = (long long)partial;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    // uniform by construction; tell the compiler so the float tail and the branches go scalar
-    int lo = __builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xFFFFFFFFll));
-    int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
-    return ((long long)hi << 32) | (unsigned)lo;
+    int lo = dpp_row_sum(partial & 0xFFFF);          // 16 x 65535 fits
+    int hi = dpp_row_sum(partial >> 16);             // arithmetic shift: signed high half
+    int slo = __builtin_amdgcn_readlane(lo, 0) + __builtin_amdgcn_readlane(lo, 16) + __builtin_amdgcn_readlane(lo, 32) + __builtin_amdgcn_readlane(lo, 48);
+    int shi = __builtin_amdgcn_readlane(hi, 0) + __builtin_amdgcn_readlane(hi, 16) + __builtin_amdgcn_readlane(hi, 32) + __builtin_amdgcn_readlane(hi, 48);
+    return (long long)shi * 65536ll + (long long)slo;
 }
 
 __device__ __forceinline__ void lk_weights(float a, float b, int& iw00, int& iw01, int& iw10, int& iw11) {
@@ -59,17 +71,27 @@ __device__ __forceinline__ void lk_weights(float a, float b, int& iw00, int& iw0
 
 struct LkCrit { int max_count; double eps2; double min_eig; };
 
+// N bytes starting at p (any alignment) into out[0..N): unaligned dword loads + byte extraction
+template <int N>
+__device__ __forceinline__ void load_bytes(const uint8_t* __restrict__ p, int (&out)[N]) {
+    constexpr int ND = (N + 3) / 4;
+    struct __attribute__((packed, aligned(1))) UD { unsigned v[ND]; };
+    const UD u = *reinterpret_cast<const UD*>(p);
+#pragma unroll
+    for (int i = 0; i < N; i++) out[i] = (int)((u.v[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+}
+
 // One cv::calcOpticalFlowPyrLK track of a single point across all pyramid levels (LKTrackerInvoker semantics,
-// SURVEY.md Appendix A.3).  (px,py) -> (outx,outy), status.  All 64 lanes call this together.
+// SURVEY.md Appendix A.3).  (px,py) -> (outx,outy), status.  All 64 lanes call this together; px, py uniform.
 template <int W>
 __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB,
-                        float px, float py, float& outx, float& outy, int& status, const LkCrit& crit,
-                        uint8_t* S, int* D, uint8_t* Jt) {
+                        float px, float py, float& outx, float& outy, int& status, const LkCrit& crit) {
     using LL = LkLayout<W>;
-    constexpr int PPL = LL::PPL, LPR = LL::LPR, SW = LL::SW, DW = LL::DW, TS = LL::TS;
+    constexpr int PPL = LL::PPL, LPR = LL::LPR, EXT = LL::EXT, NS = LL::NS, NB = LL::NB;
     const int lane = threadIdx.x;
-    const int row = lane / LPR, seg = lane - row * LPR;
-    const bool lane_on = row < W;
+    const int row_raw = lane / LPR, seg = lane - row_raw * LPR;
+    const bool lane_on = row_raw < W;
+    const int row = lane_on ? row_raw : 0;           // idle lanes shadow row 0 so their loads stay in bounds
     const int xs = seg * PPL;
     const float half = (W - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
@@ -91,49 +113,50 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             if (level == 0) status = 0;
             continue;
         }
-        // ---- stage the (W+3)^2 template tile; REFLECT_101 is the pyramid border of cv::buildOpticalFlowPyramid
-        __syncthreads();
-        for (int i = lane; i < SW * SW; i += 64) {
-            int sy = i / SW, sx = i - sy * SW;
-            S[i] = A[(size_t)reflect101(ipy - 1 + sy, L.h) * L.w + reflect101(ipx - 1 + sx, L.w)];
-        }
-        __syncthreads();
-        // ---- Scharr derivatives on the (W+1)^2 grid; zero outside the image (derivBorder = CONSTANT 0)
-        for (int i = lane; i < DW * DW; i += 64) {
-            int dy_ = i / DW, dx_ = i - dy_ * DW;
-            int gx = ipx + dx_, gy = ipy + dy_;
-            int v = 0;
-            if (gx >= 0 && gx < L.w && gy >= 0 && gy < L.h) {
-                const uint8_t* c = S + (dy_ + 1) * SW + (dx_ + 1);
-                int a00 = c[-SW - 1], a01 = c[-SW], a02 = c[-SW + 1], a10 = c[-1], a12 = c[1];
-                int a20 = c[SW - 1], a21 = c[SW], a22 = c[SW + 1];
-                int t0m = 3 * (a00 + a20) + 10 * a10, t0p = 3 * (a02 + a22) + 10 * a12;
-                int t1m = a20 - a00, t1c = a21 - a01, t1p = a22 - a02;
-                int dxv = t0p - t0m, dyv = 3 * (t1m + t1p) + 10 * t1c;
-                v = (dxv & 0xFFFF) | (dyv << 16);
+        // ---- template rows: 4 x NS source bytes per lane, origin (ipx-1+xs, ipy-1+row); REFLECT_101 = the pyramid border
+        int sv[4][NS];
+        const bool interior = ipx >= 1 && ipx + EXT + 1 < L.w && ipy >= 1 && ipy + W + 1 < L.h;
+        if (interior) {
+            const uint8_t* p = A + (size_t)(ipy - 1 + row) * L.w + (ipx - 1 + xs);
+#pragma unroll
+            for (int r = 0; r < 4; r++) load_bytes<NS>(p + (size_t)r * L.w, sv[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint8_t* rp = A + (size_t)reflect101(ipy - 1 + row + r, L.h) * L.w;
+#pragma unroll
+                for (int c = 0; c < NS; c++) sv[r][c] = rp[reflect101(ipx - 1 + xs + c, L.w)];
             }
-            D[i] = v;
         }
-        __syncthreads();
-        // ---- patch extraction into registers + covariance partials
+        // ---- Scharr derivatives at the 2 x (PPL+1) grid points this lane interpolates from; 0 outside the image
+        int dxv[2][NB], dyv[2][NB];
+#pragma unroll
+        for (int yy = 0; yy < 2; yy++)
+#pragma unroll
+            for (int xx = 0; xx < NB; xx++) {
+                int t0m = 3 * (sv[yy][xx] + sv[yy + 2][xx]) + 10 * sv[yy + 1][xx];
+                int t0p = 3 * (sv[yy][xx + 2] + sv[yy + 2][xx + 2]) + 10 * sv[yy + 1][xx + 2];
+                int t1m = sv[yy + 2][xx] - sv[yy][xx], t1c = sv[yy + 2][xx + 1] - sv[yy][xx + 1], t1p = sv[yy + 2][xx + 2] - sv[yy][xx + 2];
+                int a = t0p - t0m, b = 3 * (t1m + t1p) + 10 * t1c;
+                if (!interior) {
+                    int gx = ipx + xs + xx, gy = ipy + row + yy;
+                    if (gx < 0 || gx >= L.w || gy < 0 || gy >= L.h) { a = 0; b = 0; }
+                }
+                dxv[yy][xx] = a; dyv[yy][xx] = b;
+            }
+        // ---- patch samples (kept in registers for the Newton loop) + covariance partials
         int iw00, iw01, iw10, iw11;
         lk_weights(ppx - (float)ipx, ppy - (float)ipy, iw00, iw01, iw10, iw11);
         int Ir[PPL], Ixr[PPL], Iyr[PPL];
         int pA11 = 0, pA12 = 0, pA22 = 0;
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
-            int x = xs + j;
-            Ir[j] = 0; Ixr[j] = 0; Iyr[j] = 0;
-            if (lane_on && x < W) {
-                const uint8_t* s = S + (row + 1) * SW + (x + 1);
-                int ival = DESCALE(s[0] * iw00 + s[1] * iw01 + s[SW] * iw10 + s[SW + 1] * iw11, LK_WBITS - 5);
-                int d00 = D[row * DW + x], d01 = D[row * DW + x + 1], d10 = D[(row + 1) * DW + x], d11 = D[(row + 1) * DW + x + 1];
-                int ixval = DESCALE((int)(short)(d00 & 0xFFFF) * iw00 + (int)(short)(d01 & 0xFFFF) * iw01 +
-                                    (int)(short)(d10 & 0xFFFF) * iw10 + (int)(short)(d11 & 0xFFFF) * iw11, LK_WBITS);
-                int iyval = DESCALE((d00 >> 16) * iw00 + (d01 >> 16) * iw01 + (d10 >> 16) * iw10 + (d11 >> 16) * iw11, LK_WBITS);
-                Ir[j] = ival; Ixr[j] = ixval; Iyr[j] = iyval;
-                pA11 += ixval * ixval; pA12 += ixval * iyval; pA22 += iyval * iyval;
-            }
+            const bool on = lane_on && (xs + j < W);
+            int ival = DESCALE(__mul24(sv[1][j + 1], iw00) + __mul24(sv[1][j + 2], iw01) + __mul24(sv[2][j + 1], iw10) + __mul24(sv[2][j + 2], iw11), LK_WBITS - 5);
+            int ixval = DESCALE(__mul24(dxv[0][j], iw00) + __mul24(dxv[0][j + 1], iw01) + __mul24(dxv[1][j], iw10) + __mul24(dxv[1][j + 1], iw11), LK_WBITS);
+            int iyval = DESCALE(__mul24(dyv[0][j], iw00) + __mul24(dyv[0][j + 1], iw01) + __mul24(dyv[1][j], iw10) + __mul24(dyv[1][j + 1], iw11), LK_WBITS);
+            Ir[j] = on ? ival : 0; Ixr[j] = on ? ixval : 0; Iyr[j] = on ? iyval : 0;      // masked pixels contribute exact zeros
+            pA11 += __mul24(Ixr[j], Ixr[j]); pA12 += __mul24(Ixr[j], Iyr[j]); pA22 += __mul24(Iyr[j], Iyr[j]);
         }
         const long long iA11 = wave_sum_i64(pA11), iA12 = wave_sum_i64(pA12), iA22 = wave_sum_i64(pA22);
         const float A11 = (float)(double)iA11 * FLT_SCALE, A12 = (float)(double)iA12 * FLT_SCALE, A22 = (float)(double)iA22 * FLT_SCALE;
@@ -146,35 +169,37 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         Dt = 1.f / Dt;
         nx -= half; ny -= half;
         float pdx = 0.f, pdy = 0.f;
-        int tx0 = 0, ty0 = 0;
-        bool have_tile = false;
+        int jw[2][NB];                               // search window bytes, valid for integer origin (cinx, ciny)
+        int cinx = 0x7fffffff, ciny = 0x7fffffff;
         for (int j = 0; j < crit.max_count; j++) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
             if (inx < -W || inx >= L.w || iny < -W || iny >= L.h) {
                 if (level == 0) status = 0;
                 break;
             }
-            if (!have_tile || inx < tx0 || inx > tx0 + 2 * LK_M || iny < ty0 || iny > ty0 + 2 * LK_M) {
-                tx0 = inx - LK_M; ty0 = iny - LK_M;
-                __syncthreads();
-                for (int i = lane; i < TS * TS; i += 64) {
-                    int ty = i / TS, tx = i - ty * TS;
-                    Jt[i] = Bm[(size_t)reflect101(ty0 + ty, L.h) * L.w + reflect101(tx0 + tx, L.w)];
+            if (inx != cinx || iny != ciny) {        // the integer window moved: reload it (uniform branch)
+                cinx = inx; ciny = iny;
+                if (inx >= 0 && inx + EXT < L.w && iny >= 0 && iny + W < L.h) {
+                    const uint8_t* p = Bm + (size_t)(iny + row) * L.w + (inx + xs);
+                    load_bytes<NB>(p, jw[0]);
+                    load_bytes<NB>(p + L.w, jw[1]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const uint8_t* rp = Bm + (size_t)reflect101(iny + row + r, L.h) * L.w;
+#pragma unroll
+                        for (int c = 0; c < NB; c++) jw[r][c] = rp[reflect101(inx + xs + c, L.w)];
+                    }
                 }
-                __syncthreads();
-                have_tile = true;
             }
             lk_weights(nx - (float)inx, ny - (float)iny, iw00, iw01, iw10, iw11);
             int pb1 = 0, pb2 = 0;
-            if (lane_on) {
-                const uint8_t* jp = Jt + (iny - ty0 + row) * TS + (inx - tx0 + xs);
 #pragma unroll
-                for (int jj = 0; jj < PPL; jj++) {
-                    if (xs + jj < W) {
-                        int diff = DESCALE(jp[jj] * iw00 + jp[jj + 1] * iw01 + jp[jj + TS] * iw10 + jp[jj + TS + 1] * iw11, LK_WBITS - 5) - Ir[jj];
-                        pb1 += diff * Ixr[jj]; pb2 += diff * Iyr[jj];
-                    }
-                }
+            for (int jj = 0; jj < PPL; jj++) {
+                int v = DESCALE(__mul24(jw[0][jj], iw00) + __mul24(jw[0][jj + 1], iw01) + __mul24(jw[1][jj], iw10) + __mul24(jw[1][jj + 1], iw11), LK_WBITS - 5);
+                // masked pixels have Ix = Iy = 0, so whatever diff they see contributes an exact zero
+                int diff = v - Ir[jj];
+                pb1 += __mul24(diff, Ixr[jj]); pb2 += __mul24(diff, Iyr[jj]);
             }
             const long long ib1 = wave_sum_i64(pb1), ib2 = wave_sum_i64(pb2);
             const float b1 = (float)(double)ib1 * FLT_SCALE, b2 = (float)(double)ib2 * FLT_SCALE;
@@ -196,12 +221,6 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
     }
 }
 
-template <int W> struct LkSmem {
-    uint8_t S[(LkLayout<W>::SW * LkLayout<W>::SW + 15) & ~15];
-    int D[LkLayout<W>::DW * LkLayout<W>::DW];
-    uint8_t Jt[(LkLayout<W>::TS * LkLayout<W>::TS + 15) & ~15];
-};
-
 __device__ __forceinline__ LkCrit make_crit(const svo_config& c) {
     LkCrit k;
     int mc = c.lk_max_count; mc = mc < 0 ? 0 : (mc > 100 ? 100 : mc);       // TermCriteria normalisation (lkpyramid.cpp)
@@ -213,38 +232,38 @@ __device__ __forceinline__ LkCrit make_crit(const svo_config& c) {
 // ---- fused circular matching: L0 -> L1 -> R1 -> R0 -> L0 + masks (vo.cpp:203-230, 341-359) ----
 template <int W>
 __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d) {
-    __shared__ LkSmem<W> sm;
-    const int seq = blockIdx.y, idx = blockIdx.x;
+    const int seq = blockIdx.y;
     SeqState& s = d.st[seq];
     if (!s.active) return;
     int n = s.n_feat;
     if (d.cfg.max_features > 0 && n > d.cfg.max_features) n = d.cfg.max_features;
-    if (idx == 0 && threadIdx.x == 0) s.n_lk = n;
-    if (idx >= n) return;
-    const size_t o = (size_t)seq * d.CAP + idx;
+    if (blockIdx.x == 0 && threadIdx.x == 0) s.n_lk = n;
     const uint8_t* L0 = d.pyr + pyr_index(d, seq, s.slot_pyr_t0, 0);
     const uint8_t* R0 = d.pyr + pyr_index(d, seq, s.slot_pyr_t0, 1);
     const uint8_t* L1 = d.pyr + pyr_index(d, seq, s.slot_t1, 0);
     const uint8_t* R1 = d.pyr + pyr_index(d, seq, s.slot_t1, 1);
     const LkCrit crit = make_crit(d.cfg);
-    const float2 p0 = d.feat_xy[s.feat_buf][o];                      // pointsLeftT0 = currentVOFeatures.points (vo.cpp:338)
-    float2 p1, p2, p3, p4; int st0, st1, st2, st3;
-    lk_pass<W>(d.geom, L0, L1, p0.x, p0.y, p1.x, p1.y, st0, crit, sm.S, sm.D, sm.Jt);   // vo.cpp:203
-    lk_pass<W>(d.geom, L1, R1, p1.x, p1.y, p2.x, p2.y, st1, crit, sm.S, sm.D, sm.Jt);   // vo.cpp:206
-    lk_pass<W>(d.geom, R1, R0, p2.x, p2.y, p3.x, p3.y, st2, crit, sm.S, sm.D, sm.Jt);   // vo.cpp:209
-    lk_pass<W>(d.geom, R0, L0, p3.x, p3.y, p4.x, p4.y, st3, crit, sm.S, sm.D, sm.Jt);   // vo.cpp:213
-    if (threadIdx.x == 0) {
-        const float thr = (float)d.cfg.circular_matching_success_threshold;            // findClosePoints takes a float32 (vo.h:432)
-        float ex = fabsf(p0.x - p4.x), ey = fabsf(p0.y - p4.y);
-        float off = (ex < ey) ? ey : ex;
-        int circ = st0 && st1 && st2 && st3 && !(off > thr);                            // vo.cpp:227-230
-        const float Wf = (float)d.geom.W, Hf = (float)d.geom.H;
-        const float2 q[4] = {p0, p1, p3, p2};
-        int inb = 1;
-        for (int k = 0; k < 4; k++)
-            if ((q[k].x < 0) || (q[k].y < 0) || (q[k].y >= Hf) || (q[k].x >= Wf)) inb = 0;   // vo.cpp:344-359
-        d.pl0[o] = p0; d.pl1[o] = p1; d.pr1[o] = p2; d.pr0[o] = p3; d.plc[o] = p4;
-        d.okmask[o] = (uint8_t)(circ | (inb << 1));
+    const float thr = (float)d.cfg.circular_matching_success_threshold;                // findClosePoints takes a float32 (vo.h:432)
+    const float Wf = (float)d.geom.W, Hf = (float)d.geom.H;
+    for (int idx = blockIdx.x; idx < n; idx += gridDim.x) {
+        const size_t o = (size_t)seq * d.CAP + idx;
+        const float2 p0 = d.feat_xy[s.feat_buf][o];                  // pointsLeftT0 = currentVOFeatures.points (vo.cpp:338)
+        float2 p1, p2, p3, p4; int st0, st1, st2, st3;
+        lk_pass<W>(d.geom, L0, L1, p0.x, p0.y, p1.x, p1.y, st0, crit);   // vo.cpp:203
+        lk_pass<W>(d.geom, L1, R1, p1.x, p1.y, p2.x, p2.y, st1, crit);   // vo.cpp:206
+        lk_pass<W>(d.geom, R1, R0, p2.x, p2.y, p3.x, p3.y, st2, crit);   // vo.cpp:209
+        lk_pass<W>(d.geom, R0, L0, p3.x, p3.y, p4.x, p4.y, st3, crit);   // vo.cpp:213
+        if (threadIdx.x == 0) {
+            float ex = fabsf(p0.x - p4.x), ey = fabsf(p0.y - p4.y);
+            float off = (ex < ey) ? ey : ex;
+            int circ = st0 && st1 && st2 && st3 && !(off > thr);                        // vo.cpp:227-230
+            const float2 q[4] = {p0, p1, p3, p2};
+            int inb = 1;
+            for (int k = 0; k < 4; k++)
+                if ((q[k].x < 0) || (q[k].y < 0) || (q[k].y >= Hf) || (q[k].x >= Wf)) inb = 0;   // vo.cpp:344-359
+            d.pl0[o] = p0; d.pl1[o] = p1; d.pr1[o] = p2; d.pr0[o] = p3; d.plc[o] = p4;
+            d.okmask[o] = (uint8_t)(circ | (inb << 1));
+        }
     }
 }
 
@@ -252,17 +271,17 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d) {
 template <int W>
 __global__ __launch_bounds__(64) void k_lk_single(DevBuffers d, int slotA, int camA, int slotB, int camB, int n,
                                                   const float2* prev, float2* next, uint8_t* status) {
-    __shared__ LkSmem<W> sm;
-    const int idx = blockIdx.x;
-    if (idx >= n) return;
     const uint8_t* A = d.pyr + pyr_index(d, 0, slotA, camA);
     const uint8_t* Bp = d.pyr + pyr_index(d, 0, slotB, camB);
     const LkCrit crit = make_crit(d.cfg);
-    float2 p = prev[idx], q; int st;
-    lk_pass<W>(d.geom, A, Bp, p.x, p.y, q.x, q.y, st, crit, sm.S, sm.D, sm.Jt);
-    if (threadIdx.x == 0) { next[idx] = q; status[idx] = (uint8_t)st; }
+    for (int idx = blockIdx.x; idx < n; idx += gridDim.x) {
+        float2 p = prev[idx], q; int st;
+        lk_pass<W>(d.geom, A, Bp, p.x, p.y, q.x, q.y, st, crit);
+        if (threadIdx.x == 0) { next[idx] = q; status[idx] = (uint8_t)st; }
+    }
 }
 
+#define LK_MAX_GRID 4096
 #define LK_FOR_EACH_WINDOW(X) X(7) X(10) X(15) X(21) X(31)
 
 bool lk_window_supported(int win) {
@@ -275,6 +294,7 @@ bool lk_window_supported(int win) {
 void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
     if (grid_n < 1) grid_n = 1;
     if (grid_n > d.CAP) grid_n = d.CAP;
+    if (grid_n > LK_MAX_GRID) grid_n = LK_MAX_GRID;               // the kernel strides over features
     dim3 g(grid_n, d.B);
 #define LAUNCH(Wn) if (d.cfg.win_w == Wn) { hipLaunchKernelGGL(k_lk_chain<Wn>, g, dim3(64), 0, st, d); return; }
     LK_FOR_EACH_WINDOW(LAUNCH)
@@ -284,7 +304,7 @@ void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
 void launch_lk_single(const DevBuffers& d, int slotA, int camA, int slotB, int camB, int n, const float2* prev, float2* next,
                       uint8_t* status, hipStream_t st) {
     if (n <= 0) return;
-#define LAUNCH(Wn) if (d.cfg.win_w == Wn) { hipLaunchKernelGGL(k_lk_single<Wn>, dim3(n), dim3(64), 0, st, d, slotA, camA, slotB, camB, n, prev, next, status); return; }
+#define LAUNCH(Wn) if (d.cfg.win_w == Wn) { hipLaunchKernelGGL(k_lk_single<Wn>, dim3(n < LK_MAX_GRID ? n : LK_MAX_GRID), dim3(64), 0, st, d, slotA, camA, slotB, camB, n, prev, next, status); return; }
     LK_FOR_EACH_WINDOW(LAUNCH)
 #undef LAUNCH
 }
