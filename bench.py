@@ -48,7 +48,8 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--seqs", type=int, default=32, help="independent stereo sequences batched per GPU")
-    ap.add_argument("--depth", type=int, default=4, help="frames kept in flight per GPU (<= 8)")
+    ap.add_argument("--depth", type=int, default=4, help="frames kept in flight per context (<= 8)")
+    ap.add_argument("--contexts", type=int, default=4, help="sequence groups per GPU, each on its own HIP stream (their kernels overlap)")
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic sequences rendered per rank")
     ap.add_argument("--frames", type=int, default=10, help="frames rendered per pool sequence (ping-pong replay)")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
@@ -84,18 +85,26 @@ def main():
         p = i % (2 * F - 2)
         return p if p < F else 2 * F - 2 - p
 
-    def ptrs(step):
+    C = max(1, min(args.contexts, B))
+    while B % C:
+        C -= 1
+    Bc = B // C
+
+    def ptrs(step, c):
         lp, rp = [], []
-        for b in range(B):
+        for b in range(c * Bc, (c + 1) * Bc):
             g = b % args.pool
             f = ping_pong(step + (b // args.pool) * 3)       # phase offsets: every slot sees a different frame stream
             lp.append(left.data_ptr() + (g * F + f) * frame_bytes)
             rp.append(right.data_ptr() + (g * F + f) * frame_bytes)
         return lp, rp
 
-    vo = api.BatchVisualOdometry(W, H, B, api.default_config(**over), device=local_rank)
     Pl, Pr = syn.projection_matrices(cal)
-    vo.initalize_projection_matricies(Pl, Pr)
+    vos = []
+    for c in range(C):
+        v = api.BatchVisualOdometry(W, H, Bc, api.default_config(**over), device=local_rank)
+        v.initalize_projection_matricies(Pl, Pr)
+        vos.append(v)
 
     total = args.warmup + args.steps
     depth = max(1, min(args.depth, 8))
@@ -107,16 +116,18 @@ def main():
         sub = col = 0
         while col < count:
             while sub < count and sub - col < depth:
-                lp, rp = ptrs(first + sub)
-                vo.submit_device(lp, rp, W)
+                for c, vo in enumerate(vos):
+                    lp, rp = ptrs(first + sub, c)
+                    vo.submit_device(lp, rp, W)
                 sub += 1
-            ok, T = vo.collect()
-            if record:
-                a, b = vo.last_timing()                      # HIP events on the context's own stream
-                lk_ms.append(a); fr_ms.append(b)
-                n_lk.append(np.mean([s.n_into_lk for s in vo.stats]))
-                n_ok += int(ok.sum())
-                poses[:, col, :16] = T.reshape(B, 16); poses[:, col, 16] = ok
+            for c, vo in enumerate(vos):
+                ok, T = vo.collect()
+                if record:
+                    a, b = vo.last_timing()                  # HIP events on the context's own stream
+                    lk_ms.append(a); fr_ms.append(b)
+                    n_lk.append(np.mean([s.n_into_lk for s in vo.stats]))
+                    n_ok += int(ok.sum())
+                    poses[c * Bc:(c + 1) * Bc, col, :16] = T.reshape(Bc, 16); poses[c * Bc:(c + 1) * Bc, col, 16] = ok
             col += 1
 
     run(0, args.warmup + 1, False)                           # frame 0 only primes the pipeline (vo.cpp:47-56), then W warm-up steps
@@ -145,7 +156,7 @@ def main():
         N = float(np.mean(n_lk))
         bytes_total, bytes_lk = algorithmic_bytes(W, H, N, 21, 3, 100)
         lk_avg_ms = float(np.mean(lk_ms))
-        achieved = bytes_lk * B / (lk_avg_ms * 1e-3) / 1e9     # algorithmic GB/s of the dominant kernel (k_lk_chain)
+        achieved = bytes_lk * Bc / (lk_avg_ms * 1e-3) / 1e9    # algorithmic GB/s of the dominant kernel: one launch covers Bc sequences
         value = world * B * args.steps / dt
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_lk_chain_pmc.json")
@@ -174,7 +185,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int64/f32 (LK), f64 (PnP)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: KITTI-00 calibration, 1241x376, LK 21x21 win, maxLevel 3, 100 RANSAC-PnP iterations",
-                       "sequences_per_gpu": B, "frames_in_flight": depth, "mean_features_into_lk": N,
+                       "sequences_per_gpu": B, "contexts_per_gpu": C, "frames_in_flight": depth, "mean_features_into_lk": N,
                        "pose_ok_fraction": n_ok_all / float(world * B * args.steps)},
             "roofline": {"bound": "hbm", "kernel": "k_lk_chain<21>", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,

@@ -37,6 +37,9 @@
  *   D4. RANSAC hypotheses are scored with the EPnP rotation matrix directly instead of the
  *       R -> rvec -> R round trip through cv::Rodrigues (identity up to 1 ulp); this keeps the
  *       inlier masks free of libm (sin/cos/acos) and therefore bit-reproducible on the GPU.
+ *   D5. EPnP's 12x12 Jacobi SVD sweeps its row pairs in round-robin (Brent-Luk) order instead of OpenCV's
+ *       cyclic-by-rows order: same algorithm and convergence test, different (equally valid) pair schedule,
+ *       chosen because the n/2 pairs of a round are independent and the GPU rotates them in parallel.
  */
 #ifndef ORC_H
 #define ORC_H

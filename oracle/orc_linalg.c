@@ -7,10 +7,51 @@
 #include <math.h>
 #include <string.h>
 
+/* One Hestenes rotation of rows i < j of At (and of Vt).  Returns 1 if the pair was rotated. */
+static int rotate_pair(double* At, int m, int n, double* W, double* Vt, int i, int j) {
+    const double eps = DBL_EPSILON * 10;
+    double* Ai = At + i * m; double* Aj = At + j * m;
+    double a = W[i], p = 0, b = W[j], c, s;
+    int k;
+    for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
+    if (fabs(p) <= eps * sqrt(a * b)) return 0;
+    p *= 2;
+    double beta = a - b, gamma = sqrt(p * p + beta * beta);
+    if (beta < 0) {
+        double delta = (gamma - beta) * 0.5;
+        s = sqrt(delta / gamma);
+        c = p / (gamma * s * 2);
+    } else {
+        c = sqrt((gamma + beta) / (gamma * 2));
+        s = p / (gamma * c * 2);
+    }
+    a = b = 0;
+    for (k = 0; k < m; k++) {
+        double t0 = c * Ai[k] + s * Aj[k];
+        double t1 = -s * Ai[k] + c * Aj[k];
+        Ai[k] = t0; Aj[k] = t1;
+        a += t0 * t0; b += t1 * t1;
+    }
+    W[i] = a; W[j] = b;
+    if (Vt) {
+        double* Vi = Vt + i * n; double* Vj = Vt + j * n;
+        for (k = 0; k < n; k++) {
+            double t0 = c * Vi[k] + s * Vj[k];
+            double t1 = -s * Vi[k] + c * Vj[k];
+            Vi[k] = t0; Vj[k] = t1;
+        }
+    }
+    return 1;
+}
+
 /* At: n rows of length m (the transpose of the m x n input, m >= n). On exit rows of At are the
- * left singular vectors (for i < n1), W[n] descending, Vt n x n (rows = right singular vectors). */
-void orc_jacobi_svd(double* At, int m, int n, double* W, double* Vt, int n1) {
-    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+ * left singular vectors (for i < n1), W[n] descending, Vt n x n (rows = right singular vectors).
+ * ordering 0: cyclic by rows (i, j>i), the order OpenCV's JacobiSVDImpl_ uses.
+ * ordering 1 (n even): round-robin / Brent-Luk "circle" ordering: n-1 rounds per sweep, each round
+ *   rotating n/2 DISJOINT row pairs — the pairs of a round touch disjoint data, so a parallel
+ *   implementation (one lane per pair) produces bit-identical results to this sequential loop. */
+void orc_jacobi_svd_ord(double* At, int m, int n, double* W, double* Vt, int n1, int ordering) {
+    const double minval = DBL_MIN;
     int i, j, k, iter, max_iter = m > 30 ? m : 30;
     for (i = 0; i < n; i++) {
         double sd = 0;
@@ -20,40 +61,20 @@ void orc_jacobi_svd(double* At, int m, int n, double* W, double* Vt, int n1) {
     }
     for (iter = 0; iter < max_iter; iter++) {
         int changed = 0;
-        for (i = 0; i < n - 1; i++)
-            for (j = i + 1; j < n; j++) {
-                double* Ai = At + i * m; double* Aj = At + j * m;
-                double a = W[i], p = 0, b = W[j], c, s;
-                for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
-                if (fabs(p) <= eps * sqrt(a * b)) continue;
-                p *= 2;
-                double beta = a - b, gamma = sqrt(p * p + beta * beta);
-                if (beta < 0) {
-                    double delta = (gamma - beta) * 0.5;
-                    s = sqrt(delta / gamma);
-                    c = p / (gamma * s * 2);
-                } else {
-                    c = sqrt((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
+        if (ordering == 0 || (n & 1)) {
+            for (i = 0; i < n - 1; i++)
+                for (j = i + 1; j < n; j++) changed |= rotate_pair(At, m, n, W, Vt, i, j);
+        } else {
+            int r, q;
+            for (r = 0; r < n - 1; r++)
+                for (q = 0; q < n / 2; q++) {
+                    /* circle method: position 0 is fixed, positions 1..n-1 rotate by r */
+                    int pa = q == 0 ? 0 : 1 + (q - 1 + r) % (n - 1);
+                    int pb = 1 + (n - 1 - q - 1 + r) % (n - 1);
+                    i = pa < pb ? pa : pb; j = pa < pb ? pb : pa;
+                    changed |= rotate_pair(At, m, n, W, Vt, i, j);
                 }
-                a = b = 0;
-                for (k = 0; k < m; k++) {
-                    double t0 = c * Ai[k] + s * Aj[k];
-                    double t1 = -s * Ai[k] + c * Aj[k];
-                    Ai[k] = t0; Aj[k] = t1;
-                    a += t0 * t0; b += t1 * t1;
-                }
-                W[i] = a; W[j] = b;
-                changed = 1;
-                if (Vt) {
-                    double* Vi = Vt + i * n; double* Vj = Vt + j * n;
-                    for (k = 0; k < n; k++) {
-                        double t0 = c * Vi[k] + s * Vj[k];
-                        double t1 = -s * Vi[k] + c * Vj[k];
-                        Vi[k] = t0; Vj[k] = t1;
-                    }
-                }
-            }
+        }
         if (!changed) break;
     }
     for (i = 0; i < n; i++) {
@@ -81,6 +102,8 @@ void orc_jacobi_svd(double* At, int m, int n, double* W, double* Vt, int n1) {
         for (k = 0; k < m; k++) At[i * m + k] *= s;
     }
 }
+
+void orc_jacobi_svd(double* At, int m, int n, double* W, double* Vt, int n1) { orc_jacobi_svd_ord(At, m, n, W, Vt, n1, 0); }
 
 /* SVD of a row-major m x n matrix A (m >= n, n <= ORC_LA_MAX). Ut: n x m, Vt: n x n. */
 void orc_svd(const double* A, int m, int n, double* W, double* Ut, double* Vt) {

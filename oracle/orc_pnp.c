@@ -265,7 +265,11 @@ double orc_epnp(int n, const double* obj, const double* img, double fx, double f
             MtM[12 * i + j] = MtM[12 * j + i] = s;
         }
     }
-    orc_svd(MtM, 12, 12, W, Ut, Vt);
+    /* MtM is exactly symmetric, so it is its own transpose.  Round-robin ordering (orc_linalg.c): OpenCV uses the
+       cyclic-by-rows order; the ordering is not observable through any reference test and the parallel order is the
+       one the GPU kernel can run with 6 lanes per hypothesis, bit-identically (deviation D5 in orc.h). */
+    memcpy(Ut, MtM, sizeof(MtM));
+    orc_jacobi_svd_ord(Ut, 12, 12, W, Vt, 0, 1);
     /* L_6x10 and rho; null-space basis v[i] = Vt row 11-i (deviation D3) */
     double L[60], rho[6];
     {

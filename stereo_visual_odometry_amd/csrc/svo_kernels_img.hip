@@ -324,12 +324,15 @@ __global__ void k_bucket_offer_old(DevBuffers d, int pass) {
     }
 }
 
-// one 1024-thread block per sequence: scan the grid in raster order, emit winners
-__global__ __launch_bounds__(1024) void k_bucket_emit(DevBuffers d, int pass) {
+// one 256-thread block per sequence (small enough to be placed beside another context's LK waves):
+// scan the grid in raster order, emit winners
+#define SCAN_THREADS 256
+#define SCAN_WAVES (SCAN_THREADS / 64)
+__global__ __launch_bounds__(SCAN_THREADS) void k_bucket_emit(DevBuffers d, int pass) {
     const int seq = blockIdx.x;
     SeqState& s = d.st[seq];
     if (pass == 0 ? !s.active : !s.do_second) return;
-    __shared__ int wave_tot[16];
+    __shared__ int wave_tot[SCAN_WAVES];
     __shared__ int s_total;
     const int fb = s.feat_buf, nb = d.NB, n_old = s.n_old, W = d.geom.W;
     const unsigned long long* keys = d.bucket_keys + (size_t)seq * nb;
@@ -339,8 +342,8 @@ __global__ __launch_bounds__(1024) void k_bucket_emit(DevBuffers d, int pass) {
     float2* nxy = d.feat_xy[fb ^ 1] + (size_t)seq * d.CAP;
     int* nage = d.feat_age[fb ^ 1] + (size_t)seq * d.CAP;
     int* nstr = d.feat_str[fb ^ 1] + (size_t)seq * d.CAP;
-    const int chunk = (nb + 1023) / 1024;
-    const int b0 = threadIdx.x * chunk, b1 = (b0 + chunk < nb) ? b0 + chunk : nb;
+    const int chunk = (nb + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int b0 = threadIdx.x * chunk < nb ? threadIdx.x * chunk : nb, b1 = (b0 + chunk < nb) ? b0 + chunk : nb;
     int cnt = 0;
     for (int b = b0; b < b1; b++) cnt += keys[b] != 0ull;
     // block exclusive scan of cnt
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(1024) void k_bucket_emit(DevBuffers d, int pass) {
     for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
     if (lane == 63) wave_tot[wv] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < 16; i++) { int t = wave_tot[i]; wave_tot[i] = acc; acc += t; } s_total = acc; }
+    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < SCAN_WAVES; i++) { int t = wave_tot[i]; wave_tot[i] = acc; acc += t; } s_total = acc; }
     __syncthreads();
     int pos = wave_tot[wv] + incl - cnt;
     for (int b = b0; b < b1; b++) {
@@ -379,11 +382,11 @@ __global__ __launch_bounds__(1024) void k_bucket_emit(DevBuffers d, int pass) {
 void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t st) {
     int th = pass == 0 ? d.cfg.fast_threshold : d.cfg.fast_threshold / 4;            // vo.cpp:325 / :329-330
     if (th_override >= 0) th = th_override;
-    hipLaunchKernelGGL(k_bucket_clear, dim3((d.NB + 1023) / 1024, d.B), dim3(1024), 0, st, d, pass);
+    hipLaunchKernelGGL(k_bucket_clear, dim3((d.NB + 255) / 256, d.B), dim3(256), 0, st, d, pass);
     hipLaunchKernelGGL(k_bucket_offer_old, dim3((d.CAP + 255) / 256, d.B), dim3(256), 0, st, d, pass);
     dim3 g((d.geom.W + FT_W - 1) / FT_W, (d.geom.H + FT_H - 1) / FT_H, d.B);
     hipLaunchKernelGGL(k_fast<true>, g, dim3(256), 0, st, (const uint8_t*)nullptr, 0, 0, (uint8_t*)nullptr, d, pass, th);
-    hipLaunchKernelGGL(k_bucket_emit, dim3(d.B), dim3(1024), 0, st, d, pass);
+    hipLaunchKernelGGL(k_bucket_emit, dim3(d.B), dim3(SCAN_THREADS), 0, st, d, pass);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -440,18 +443,18 @@ void launch_bucket_general(int img_w, int img_h, int n, const float2* xy, const 
 // Stable compaction after circular matching + in-bounds mask (deletePointsWithFailureStatus /
 // deleteFeaturesWithFailureStatus, vo.cpp:144-168, called at :233-238 and :360-364), fused with
 // ages[i] += 1 (vo.cpp:70-72) and the "too few tracks" gate (vo.cpp:82-84).
-// One 1024-thread block per sequence, order-preserving prefix sum.
+// One 256-thread block per sequence, order-preserving prefix sum.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_compact(DevBuffers d) {
+__global__ __launch_bounds__(SCAN_THREADS) void k_compact(DevBuffers d) {
     const int seq = blockIdx.x;
     SeqState& s = d.st[seq];
     if (!s.active) return;
-    __shared__ int wave_tot[16], wave_tot_c[16];
+    __shared__ int wave_tot[SCAN_WAVES], wave_tot_c[SCAN_WAVES];
     __shared__ int s_total, s_total_c;
     const int n = s.n_lk, fb = s.feat_buf;
     const size_t o = (size_t)seq * d.CAP;
-    const int chunk = (n + 1023) / 1024;
-    const int i0 = threadIdx.x * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
+    const int chunk = (n + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int i0 = threadIdx.x * chunk < n ? threadIdx.x * chunk : n, i1 = (i0 + chunk < n) ? i0 + chunk : n;
     int cnt = 0, cntc = 0;
     for (int i = i0; i < i1; i++) { uint8_t m = d.okmask[o + i]; cnt += (m == 3); cntc += (m & 1); }
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(1024) void k_compact(DevBuffers d) {
     __syncthreads();
     if (threadIdx.x == 0) {
         int acc = 0, accc = 0;
-        for (int i = 0; i < 16; i++) { int t = wave_tot[i]; wave_tot[i] = acc; acc += t; accc += wave_tot_c[i]; }
+        for (int i = 0; i < SCAN_WAVES; i++) { int t = wave_tot[i]; wave_tot[i] = acc; acc += t; accc += wave_tot_c[i]; }
         s_total = acc; s_total_c = accc;
     }
     __syncthreads();
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(1024) void k_compact(DevBuffers d) {
     }
 }
 void launch_compact(const DevBuffers& d, hipStream_t st) {
-    hipLaunchKernelGGL(k_compact, dim3(d.B), dim3(1024), 0, st, d);
+    hipLaunchKernelGGL(k_compact, dim3(d.B), dim3(SCAN_THREADS), 0, st, d);
 }
 
 // findClosePoints (vo.cpp:265-280) as a stand-alone stage

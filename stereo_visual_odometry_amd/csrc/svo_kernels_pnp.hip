@@ -70,45 +70,178 @@ __global__ void k_pnp_subsets(DevBuffers d) {
 }
 
 // ------------------------------------------------------------------------------------------------ EPnP on 5 points
-struct Epnp5 {
-    double fu, fv, uc, vc;
-    double pws[15], us[10], alphas[20], pcs[15];
-    double cws[4][3], ccs[4][3];
-};
+// 8 lanes cooperate on one hypothesis (8 hypotheses per 64-thread block); every array lives in an LDS arena
+// (no scratch memory).  The 12x12 one-sided Jacobi SVD of MtM — 85 % of EPnP's work — sweeps its row pairs in
+// round-robin order: the 6 pairs of a round are disjoint, so lanes 0..5 rotate them in parallel and the result is
+// bit-identical to the sequential round-robin loop.  The three beta approximations (N = 4, 2, 3 null vectors) are
+// independent after L and rho and run on lanes 0..2.
+#define EP_G 8                                   // lanes per hypothesis
+#define EP_HPB 8                                 // hypotheses per block
+#define EP_STRIDE 1032                           // doubles per hypothesis (+8 pad: distinct LDS banks per hypothesis)
+// arena map (doubles)
+#define EA_AT 0                                  // 144  MtM, then the rotating rows
+#define EA_VT 144                                // 144
+#define EA_W 288                                 // 12
+#define EA_M 300                                 // 120  (dead after MtM is built)
+#define EA_PWS 420                               // 15
+#define EA_US 435                                // 10
+#define EA_AL 445                                // 20
+#define EA_CWS 465                               // 12
+#define EA_L 480                                 // 60
+#define EA_RHO 540                               // 6
+#define EA_RES 552                               // 3 x 13: rep, R[9], t[3] of the three branches
+#define EA_BR 600                                // 3 x 140 branch workspaces
+#define EA_BRSZ 140
+
 static __device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 static __device__ __forceinline__ double dist2(const double* a, const double* b) {
     return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
 }
 
-static __device__ double epnp_compute_R_and_t(Epnp5& e, const double* vt, const double* betas, double R[9], double t[3]) {
+// one Hestenes rotation of rows i < j (12 x 12), Vt rotated alongside; returns true if the pair was rotated
+static __device__ bool rotate_pair12(double* At, double* Wv, double* Vt, int i, int j) {
+    const double eps = SVO_DBL_EPS * 10;
+    double* Ai = At + i * 12; double* Aj = At + j * 12;
+    double a = Wv[i], p = 0, b = Wv[j], c, s;
+    for (int k = 0; k < 12; k++) p += Ai[k] * Aj[k];
+    if (fabs(p) <= eps * sqrt(a * b)) return false;
+    p *= 2;
+    double beta = a - b, gamma = sqrt(p * p + beta * beta);
+    if (beta < 0) {
+        double delta = (gamma - beta) * 0.5;
+        s = sqrt(delta / gamma);
+        c = p / (gamma * s * 2);
+    } else {
+        c = sqrt((gamma + beta) / (gamma * 2));
+        s = p / (gamma * c * 2);
+    }
+    a = b = 0;
+    for (int k = 0; k < 12; k++) {
+        double t0 = c * Ai[k] + s * Aj[k];
+        double t1 = -s * Ai[k] + c * Aj[k];
+        Ai[k] = t0; Aj[k] = t1;
+        a += t0 * t0; b += t1 * t1;
+    }
+    Wv[i] = a; Wv[j] = b;
+    double* Vi = Vt + i * 12; double* Vj = Vt + j * 12;
+    for (int k = 0; k < 12; k++) {
+        double t0 = c * Vi[k] + s * Vj[k];
+        double t1 = -s * Vi[k] + c * Vj[k];
+        Vi[k] = t0; Vj[k] = t1;
+    }
+    return true;
+}
+
+// x = pinv(A) b (A: M x N row-major) through a cyclic one-sided Jacobi SVD; workspace ws needs N*M + N*N + N doubles
+template <int M, int N>
+static __device__ void svd_solve_ws(const double* A, const double* b, double* x, double* ws) {
+    double* Ut = ws; double* Vt = ws + N * M; double* Wv = Vt + N * N;
+    for (int i = 0; i < N; i++) for (int j = 0; j < M; j++) Ut[i * M + j] = A[j * N + i];
+    jacobi_svd<M, N>(Ut, Wv, Vt, N);
+    double thr = 0;
+    for (int i = 0; i < N; i++) thr += Wv[i];
+    thr *= SVO_DBL_EPS * 2;
+    for (int k = 0; k < N; k++) x[k] = 0;
+    for (int i = 0; i < N; i++) {
+        if (Wv[i] <= thr) continue;
+        double s = 0;
+        for (int k = 0; k < M; k++) s += Ut[i * M + k] * b[k];
+        s /= Wv[i];
+        for (int k = 0; k < N; k++) x[k] += s * Vt[i * N + k];
+    }
+}
+
+// Householder QR least squares for the 6 x 4 Gauss-Newton step; everything in the workspace (A 24, b 6, x 4, A1 4, A2 4)
+static __device__ bool qr_solve64(double* A, double* b, double* x, double* A1, double* A2) {
+    const int M = 6, N = 4;
+    for (int k = 0; k < N; k++) {
+        double eta = 0;
+        for (int i = k; i < M; i++) { double e = fabs(A[i * N + k]); if (eta < e) eta = e; }
+        if (eta == 0) return false;
+        double sum2 = 0, inv_eta = 1. / eta;
+        for (int i = k; i < M; i++) { A[i * N + k] *= inv_eta; sum2 += A[i * N + k] * A[i * N + k]; }
+        double sigma = sqrt(sum2);
+        if (A[k * N + k] < 0) sigma = -sigma;
+        A[k * N + k] += sigma;
+        A1[k] = sigma * A[k * N + k];
+        A2[k] = -eta * sigma;
+        for (int j = k + 1; j < N; j++) {
+            double sum = 0;
+            for (int i = k; i < M; i++) sum += A[i * N + k] * A[i * N + j];
+            double tau = sum / A1[k];
+            for (int i = k; i < M; i++) A[i * N + j] -= tau * A[i * N + k];
+        }
+    }
+    for (int j = 0; j < N; j++) {
+        double tau = 0;
+        for (int i = j; i < M; i++) tau += A[i * N + j] * b[i];
+        tau /= A1[j];
+        for (int i = j; i < M; i++) b[i] -= tau * A[i * N + j];
+    }
+    x[N - 1] = b[N - 1] / A2[N - 1];
+    for (int i = N - 2; i >= 0; i--) {
+        double sum = 0;
+        for (int j = i + 1; j < N; j++) sum += A[i * N + j] * x[j];
+        x[i] = (b[i] - sum) / A2[i];
+    }
+    return true;
+}
+
+static __device__ void epnp_gauss_newton(const double* L, const double* rho, double* betas, double* ws) {
+    double* A = ws; double* B = ws + 24; double* X = ws + 30; double* A1 = ws + 34; double* A2 = ws + 38;
+    for (int it = 0; it < 5; it++) {
+        const double b0 = betas[0], b1 = betas[1], b2 = betas[2], b3 = betas[3];
+        for (int i = 0; i < 6; i++) {
+            const double* rl = L + 10 * i; double* ra = A + 4 * i;
+            ra[0] = 2 * rl[0] * b0 + rl[1] * b1 + rl[3] * b2 + rl[6] * b3;
+            ra[1] = rl[1] * b0 + 2 * rl[2] * b1 + rl[4] * b2 + rl[7] * b3;
+            ra[2] = rl[3] * b0 + rl[4] * b1 + 2 * rl[5] * b2 + rl[8] * b3;
+            ra[3] = rl[6] * b0 + rl[7] * b1 + rl[8] * b2 + 2 * rl[9] * b3;
+            B[i] = rho[i] - (rl[0] * b0 * b0 + rl[1] * b0 * b1 + rl[2] * b1 * b1 +
+                             rl[3] * b0 * b2 + rl[4] * b1 * b2 + rl[5] * b2 * b2 +
+                             rl[6] * b0 * b3 + rl[7] * b1 * b3 + rl[8] * b2 * b3 +
+                             rl[9] * b3 * b3);
+        }
+        if (!qr_solve64(A, B, X, A1, A2)) return;
+        for (int i = 0; i < 4; i++) betas[i] += X[i];
+    }
+}
+
+// compute_ccs, compute_pcs, solve_for_sign, estimate_R_and_t (Arun / Horn), reprojection_error.  ws: >= 66 doubles.
+static __device__ double epnp_compute_R_and_t(const double* ar, const double* betas, double* R, double* t, double* ws,
+                                              double fu, double fv, double uc, double vc) {
     const int n = 5;
-    for (int i = 0; i < 4; i++) e.ccs[i][0] = e.ccs[i][1] = e.ccs[i][2] = 0.0;
+    const double* vt = ar + EA_VT; const double* alphas = ar + EA_AL; const double* pws = ar + EA_PWS; const double* us = ar + EA_US;
+    double* ccs = ws; double* pcs = ws + 12; double* abt = ws + 27; double* Wv = ws + 36; double* Ut = ws + 39; double* Vt = ws + 48;
+    double* pc0 = ws + 57; double* pw0 = ws + 60;
+    for (int i = 0; i < 12; i++) ccs[i] = 0.0;
     for (int i = 0; i < 4; i++) {
         const double* v = vt + 12 * (11 - i);
-        for (int j = 0; j < 4; j++) for (int k = 0; k < 3; k++) e.ccs[j][k] += betas[i] * v[3 * j + k];
+        const double be = betas[i];
+        for (int j = 0; j < 4; j++) for (int k = 0; k < 3; k++) ccs[3 * j + k] += be * v[3 * j + k];
     }
     for (int i = 0; i < n; i++) {
-        const double* a = e.alphas + 4 * i; double* pc = e.pcs + 3 * i;
-        for (int j = 0; j < 3; j++) pc[j] = a[0] * e.ccs[0][j] + a[1] * e.ccs[1][j] + a[2] * e.ccs[2][j] + a[3] * e.ccs[3][j];
+        const double* a = alphas + 4 * i; double* pc = pcs + 3 * i;
+        for (int j = 0; j < 3; j++) pc[j] = a[0] * ccs[j] + a[1] * ccs[3 + j] + a[2] * ccs[6 + j] + a[3] * ccs[9 + j];
     }
-    if (e.pcs[2] < 0.0) {
-        for (int i = 0; i < 4; i++) for (int j = 0; j < 3; j++) e.ccs[i][j] = -e.ccs[i][j];
-        for (int i = 0; i < 3 * n; i++) e.pcs[i] = -e.pcs[i];
+    if (pcs[2] < 0.0) {
+        for (int i = 0; i < 12; i++) ccs[i] = -ccs[i];
+        for (int i = 0; i < 3 * n; i++) pcs[i] = -pcs[i];
     }
-    // estimate_R_and_t (Arun / Horn)
-    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0}, abt[9], Wv[3], Ut[9], Vt[9];
-    for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) { pc0[j] += e.pcs[3 * i + j]; pw0[j] += e.pws[3 * i + j]; }
+    for (int j = 0; j < 3; j++) { pc0[j] = 0; pw0[j] = 0; }
+    for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) { pc0[j] += pcs[3 * i + j]; pw0[j] += pws[3 * i + j]; }
     for (int j = 0; j < 3; j++) { pc0[j] /= n; pw0[j] /= n; }
     for (int i = 0; i < 9; i++) abt[i] = 0;
     for (int i = 0; i < n; i++) {
-        const double* pc = e.pcs + 3 * i; const double* pw = e.pws + 3 * i;
+        const double* pc = pcs + 3 * i; const double* pw = pws + 3 * i;
         for (int j = 0; j < 3; j++) {
             abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
             abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
             abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
         }
     }
-    svd_rm<3, 3>(abt, Wv, Ut, Vt);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ut[i * 3 + j] = abt[j * 3 + i];
+    jacobi_svd<3, 3>(Ut, Wv, Vt, 3);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
         double s = 0;
         for (int k = 0; k < 3; k++) s += Ut[k * 3 + i] * Vt[k * 3 + j];
@@ -118,180 +251,205 @@ static __device__ double epnp_compute_R_and_t(Epnp5& e, const double* vt, const 
                - R[2] * R[4] * R[6] - R[1] * R[3] * R[8] - R[0] * R[5] * R[7];
     if (det < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
     for (int i = 0; i < 3; i++) t[i] = pc0[i] - dot3(R + 3 * i, pw0);
-    // reprojection_error
     double sum2 = 0.0;
     for (int i = 0; i < n; i++) {
-        const double* pw = e.pws + 3 * i;
+        const double* pw = pws + 3 * i;
         double Xc = dot3(R, pw) + t[0], Yc = dot3(R + 3, pw) + t[1], inv_Zc = 1.0 / (dot3(R + 6, pw) + t[2]);
-        double ue = e.uc + e.fu * Xc * inv_Zc, ve = e.vc + e.fv * Yc * inv_Zc;
-        double u = e.us[2 * i], v = e.us[2 * i + 1];
+        double ue = uc + fu * Xc * inv_Zc, ve = vc + fv * Yc * inv_Zc;
+        double u = us[2 * i], v = us[2 * i + 1];
         sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
     }
     return sum2 / n;
 }
 
-static __device__ void epnp_gauss_newton(const double* L, const double* rho, double betas[4]) {
-    for (int it = 0; it < 5; it++) {
-        double A[24], B[6], X[4];
-        for (int i = 0; i < 6; i++) {
-            const double* rl = L + 10 * i; double* ra = A + 4 * i;
-            ra[0] = 2 * rl[0] * betas[0] + rl[1] * betas[1] + rl[3] * betas[2] + rl[6] * betas[3];
-            ra[1] = rl[1] * betas[0] + 2 * rl[2] * betas[1] + rl[4] * betas[2] + rl[7] * betas[3];
-            ra[2] = rl[3] * betas[0] + rl[4] * betas[1] + 2 * rl[5] * betas[2] + rl[8] * betas[3];
-            ra[3] = rl[6] * betas[0] + rl[7] * betas[1] + rl[8] * betas[2] + 2 * rl[9] * betas[3];
-            B[i] = rho[i] - (rl[0] * betas[0] * betas[0] + rl[1] * betas[0] * betas[1] + rl[2] * betas[1] * betas[1] +
-                             rl[3] * betas[0] * betas[2] + rl[4] * betas[1] * betas[2] + rl[5] * betas[2] * betas[2] +
-                             rl[6] * betas[0] * betas[3] + rl[7] * betas[1] * betas[3] + rl[8] * betas[2] * betas[3] +
-                             rl[9] * betas[3] * betas[3]);
-        }
-        if (!qr_solve<6, 4>(A, B, X)) return;
-        for (int i = 0; i < 4; i++) betas[i] += X[i];
-    }
-}
-
-static __device__ void epnp5(const double* obj, const double* img, double fx, double fy, double cx, double cy, double R[9], double t[3]) {
+// phase 1 (one lane): control points, barycentric coordinates, M, MtM -> arena; W = squared row norms, Vt = I
+static __device__ void epnp_setup(double* ar, double fu, double fv, double uc, double vc) {
     const int n = 5;
-    Epnp5 e;
-    e.fu = fx; e.fv = fy; e.uc = cx; e.vc = cy;
-    for (int i = 0; i < 15; i++) e.pws[i] = obj[i];
-    for (int i = 0; i < 10; i++) e.us[i] = img[i];
-    // control points: centroid + PCA axes
-    for (int j = 0; j < 3; j++) e.cws[0][j] = 0;
-    for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) e.cws[0][j] += e.pws[3 * i + j];
-    for (int j = 0; j < 3; j++) e.cws[0][j] /= n;
+    double* pws = ar + EA_PWS; double* us = ar + EA_US; double* alphas = ar + EA_AL; double* cws = ar + EA_CWS;
+    for (int j = 0; j < 3; j++) cws[j] = 0;
+    for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) cws[j] += pws[3 * i + j];
+    for (int j = 0; j < 3; j++) cws[j] /= n;
     {
         double ptp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dc[3], ut[9], vt3[9];
         for (int i = 0; i < n; i++) {
             double dd[3];
-            for (int j = 0; j < 3; j++) dd[j] = e.pws[3 * i + j] - e.cws[0][j];
+            for (int j = 0; j < 3; j++) dd[j] = pws[3 * i + j] - cws[j];
             for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) ptp[3 * j + k] += dd[j] * dd[k];
         }
         svd_rm<3, 3>(ptp, dc, ut, vt3);
         for (int i = 1; i < 4; i++) {
             double kk = sqrt(dc[i - 1] / n);
-            for (int j = 0; j < 3; j++) e.cws[i][j] = e.cws[0][j] + kk * vt3[3 * (i - 1) + j];
+            for (int j = 0; j < 3; j++) cws[3 * i + j] = cws[j] + kk * vt3[3 * (i - 1) + j];
         }
     }
-    {   // barycentric coordinates
+    {
         double cc[9], ci[9];
-        for (int i = 0; i < 3; i++) for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = e.cws[j][i] - e.cws[0][i];
+        for (int i = 0; i < 3; i++) for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = cws[3 * j + i] - cws[i];
         inv3_svd(cc, ci);
         for (int i = 0; i < n; i++) {
-            const double* pi = e.pws + 3 * i; double* a = e.alphas + 4 * i;
+            const double* pi = pws + 3 * i; double* a = alphas + 4 * i;
             for (int j = 0; j < 3; j++)
-                a[1 + j] = ci[3 * j] * (pi[0] - e.cws[0][0]) + ci[3 * j + 1] * (pi[1] - e.cws[0][1]) + ci[3 * j + 2] * (pi[2] - e.cws[0][2]);
+                a[1 + j] = ci[3 * j] * (pi[0] - cws[0]) + ci[3 * j + 1] * (pi[1] - cws[1]) + ci[3 * j + 2] * (pi[2] - cws[2]);
             a[0] = 1.0 - a[1] - a[2] - a[3];
         }
     }
-    double MtM[144], Wv[12], Ut[144], Vt[144];
-    {
-        double M[120];
-        for (int i = 0; i < n; i++) {
-            double* M1 = M + 24 * i; double* M2 = M1 + 12; const double* as = e.alphas + 4 * i;
-            double u = e.us[2 * i], v = e.us[2 * i + 1];
-            for (int j = 0; j < 4; j++) {
-                M1[3 * j] = as[j] * e.fu; M1[3 * j + 1] = 0.0; M1[3 * j + 2] = as[j] * (e.uc - u);
-                M2[3 * j] = 0.0; M2[3 * j + 1] = as[j] * e.fv; M2[3 * j + 2] = as[j] * (e.vc - v);
-            }
-        }
-        for (int i = 0; i < 12; i++) for (int j = i; j < 12; j++) {
-            double s = 0;
-            for (int k = 0; k < 2 * n; k++) s += M[12 * k + i] * M[12 * k + j];
-            MtM[12 * i + j] = MtM[12 * j + i] = s;
+    double* M = ar + EA_M; double* MtM = ar + EA_AT; double* Vt = ar + EA_VT; double* Wv = ar + EA_W;
+    for (int i = 0; i < n; i++) {
+        double* M1 = M + 24 * i; double* M2 = M1 + 12; const double* as = alphas + 4 * i;
+        double u = us[2 * i], v = us[2 * i + 1];
+        for (int j = 0; j < 4; j++) {
+            M1[3 * j] = as[j] * fu; M1[3 * j + 1] = 0.0; M1[3 * j + 2] = as[j] * (uc - u);
+            M2[3 * j] = 0.0; M2[3 * j + 1] = as[j] * fv; M2[3 * j + 2] = as[j] * (vc - v);
         }
     }
-    svd_rm<12, 12>(MtM, Wv, Ut, Vt);
-    double L[60], rho[6];
-    {
-        double dv[4][6][3];
-        for (int i = 0; i < 4; i++) {
-            const double* v = Vt + 12 * (11 - i);
-            int a = 0, b = 1;
-            for (int j = 0; j < 6; j++) {
-                for (int k = 0; k < 3; k++) dv[i][j][k] = v[3 * a + k] - v[3 * b + k];
-                b++;
-                if (b > 3) { a++; b = a + 1; }
-            }
-        }
-        for (int i = 0; i < 6; i++) {
-            double* row = L + 10 * i;
-            row[0] = dot3(dv[0][i], dv[0][i]);
-            row[1] = 2.0 * dot3(dv[0][i], dv[1][i]);
-            row[2] = dot3(dv[1][i], dv[1][i]);
-            row[3] = 2.0 * dot3(dv[0][i], dv[2][i]);
-            row[4] = 2.0 * dot3(dv[1][i], dv[2][i]);
-            row[5] = dot3(dv[2][i], dv[2][i]);
-            row[6] = 2.0 * dot3(dv[0][i], dv[3][i]);
-            row[7] = 2.0 * dot3(dv[1][i], dv[3][i]);
-            row[8] = 2.0 * dot3(dv[2][i], dv[3][i]);
-            row[9] = dot3(dv[3][i], dv[3][i]);
-        }
-        rho[0] = dist2(e.cws[0], e.cws[1]); rho[1] = dist2(e.cws[0], e.cws[2]); rho[2] = dist2(e.cws[0], e.cws[3]);
-        rho[3] = dist2(e.cws[1], e.cws[2]); rho[4] = dist2(e.cws[1], e.cws[3]); rho[5] = dist2(e.cws[2], e.cws[3]);
+    for (int i = 0; i < 12; i++) for (int j = i; j < 12; j++) {
+        double s = 0;
+        for (int k = 0; k < 2 * n; k++) s += M[12 * k + i] * M[12 * k + j];
+        MtM[12 * i + j] = MtM[12 * j + i] = s;
     }
-    double be[4], rep[4], Rs[4][9], ts[4][3];
-    {
-        double L4[24], b4[4];
-        for (int i = 0; i < 6; i++) { L4[4 * i] = L[10 * i]; L4[4 * i + 1] = L[10 * i + 1]; L4[4 * i + 2] = L[10 * i + 3]; L4[4 * i + 3] = L[10 * i + 6]; }
-        svd_solve<6, 4>(L4, rho, b4);
-        if (b4[0] < 0) { be[0] = sqrt(-b4[0]); be[1] = -b4[1] / be[0]; be[2] = -b4[2] / be[0]; be[3] = -b4[3] / be[0]; }
-        else { be[0] = sqrt(b4[0]); be[1] = b4[1] / be[0]; be[2] = b4[2] / be[0]; be[3] = b4[3] / be[0]; }
-        epnp_gauss_newton(L, rho, be);
-        rep[1] = epnp_compute_R_and_t(e, Vt, be, Rs[1], ts[1]);
+    // MtM is exactly symmetric, i.e. its own transpose: the one-sided Jacobi runs in place on it
+    for (int i = 0; i < 12; i++) {
+        double sd = 0;
+        for (int k = 0; k < 12; k++) { double tt = MtM[i * 12 + k]; sd += tt * tt; }
+        Wv[i] = sd;
+        for (int k = 0; k < 12; k++) Vt[i * 12 + k] = 0;
+        Vt[i * 12 + i] = 1;
     }
-    {
-        double L3[18], b3[3];
-        for (int i = 0; i < 6; i++) { L3[3 * i] = L[10 * i]; L3[3 * i + 1] = L[10 * i + 1]; L3[3 * i + 2] = L[10 * i + 2]; }
-        svd_solve<6, 3>(L3, rho, b3);
-        if (b3[0] < 0) { be[0] = sqrt(-b3[0]); be[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
-        else { be[0] = sqrt(b3[0]); be[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
-        if (b3[1] < 0) be[0] = -be[0];
-        be[2] = 0.0; be[3] = 0.0;
-        epnp_gauss_newton(L, rho, be);
-        rep[2] = epnp_compute_R_and_t(e, Vt, be, Rs[2], ts[2]);
-    }
-    {
-        double L5[30], b5[5];
-        for (int i = 0; i < 6; i++) for (int j = 0; j < 5; j++) L5[5 * i + j] = L[10 * i + j];
-        svd_solve<6, 5>(L5, rho, b5);
-        if (b5[0] < 0) { be[0] = sqrt(-b5[0]); be[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
-        else { be[0] = sqrt(b5[0]); be[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
-        if (b5[1] < 0) be[0] = -be[0];
-        be[2] = b5[3] / be[0];
-        be[3] = 0.0;
-        epnp_gauss_newton(L, rho, be);
-        rep[3] = epnp_compute_R_and_t(e, Vt, be, Rs[3], ts[3]);
-    }
-    int N = 1;
-    if (rep[2] < rep[1]) N = 2;
-    if (rep[3] < rep[N]) N = 3;
-    for (int i = 0; i < 9; i++) R[i] = Rs[N][i];
-    for (int i = 0; i < 3; i++) t[i] = ts[N][i];
 }
 
-__global__ __launch_bounds__(64) void k_pnp_epnp(DevBuffers d) {
+// phase 3 (one lane): singular values, the descending selection sort applied to Vt, then L (6x10) and rho
+static __device__ void epnp_sort_and_L(double* ar) {
+    double* At = ar + EA_AT; double* Vt = ar + EA_VT; double* Wv = ar + EA_W; double* cws = ar + EA_CWS;
+    for (int i = 0; i < 12; i++) {
+        double sd = 0;
+        for (int k = 0; k < 12; k++) { double tt = At[i * 12 + k]; sd += tt * tt; }
+        Wv[i] = sqrt(sd);
+    }
+    for (int i = 0; i < 11; i++) {
+        int j = i;
+        for (int k = i + 1; k < 12; k++) if (Wv[j] < Wv[k]) j = k;
+        if (i != j) {
+            double tt = Wv[i]; Wv[i] = Wv[j]; Wv[j] = tt;
+            for (int k = 0; k < 12; k++) { tt = Vt[i * 12 + k]; Vt[i * 12 + k] = Vt[j * 12 + k]; Vt[j * 12 + k] = tt; }
+        }
+    }
+    double* L = ar + EA_L; double* rho = ar + EA_RHO;
+    double* dv = At;                               // 4 x 6 x 3 scratch in the dead At region
+    for (int i = 0; i < 4; i++) {
+        const double* v = Vt + 12 * (11 - i);
+        int a = 0, b = 1;
+        for (int j = 0; j < 6; j++) {
+            for (int k = 0; k < 3; k++) dv[(i * 6 + j) * 3 + k] = v[3 * a + k] - v[3 * b + k];
+            b++;
+            if (b > 3) { a++; b = a + 1; }
+        }
+    }
+    for (int i = 0; i < 6; i++) {
+        double* row = L + 10 * i;
+        const double* d0 = dv + (0 * 6 + i) * 3; const double* d1 = dv + (1 * 6 + i) * 3;
+        const double* d2 = dv + (2 * 6 + i) * 3; const double* d3 = dv + (3 * 6 + i) * 3;
+        row[0] = dot3(d0, d0);
+        row[1] = 2.0 * dot3(d0, d1);
+        row[2] = dot3(d1, d1);
+        row[3] = 2.0 * dot3(d0, d2);
+        row[4] = 2.0 * dot3(d1, d2);
+        row[5] = dot3(d2, d2);
+        row[6] = 2.0 * dot3(d0, d3);
+        row[7] = 2.0 * dot3(d1, d3);
+        row[8] = 2.0 * dot3(d2, d3);
+        row[9] = dot3(d3, d3);
+    }
+    rho[0] = dist2(cws, cws + 3); rho[1] = dist2(cws, cws + 6); rho[2] = dist2(cws, cws + 9);
+    rho[3] = dist2(cws + 3, cws + 6); rho[4] = dist2(cws + 3, cws + 9); rho[5] = dist2(cws + 6, cws + 9);
+}
+
+// phase 4 (lanes 0..2): beta approximation `branch` (1: N=4 null vectors, 2: N=2, 3: N=3), Gauss-Newton, R, t, error
+static __device__ void epnp_branch(double* ar, int branch, double fu, double fv, double uc, double vc) {
+    const double* L = ar + EA_L; const double* rho = ar + EA_RHO;
+    double* ws = ar + EA_BR + (branch - 1) * EA_BRSZ;
+    double* Lx = ws + 70; double* bx = ws + 100; double* be = ws + 106;       // svd workspace occupies ws[0, 60)
+    if (branch == 1) {
+        for (int i = 0; i < 6; i++) { Lx[4 * i] = L[10 * i]; Lx[4 * i + 1] = L[10 * i + 1]; Lx[4 * i + 2] = L[10 * i + 3]; Lx[4 * i + 3] = L[10 * i + 6]; }
+        svd_solve_ws<6, 4>(Lx, rho, bx, ws);
+        if (bx[0] < 0) { be[0] = sqrt(-bx[0]); be[1] = -bx[1] / be[0]; be[2] = -bx[2] / be[0]; be[3] = -bx[3] / be[0]; }
+        else { be[0] = sqrt(bx[0]); be[1] = bx[1] / be[0]; be[2] = bx[2] / be[0]; be[3] = bx[3] / be[0]; }
+    } else if (branch == 2) {
+        for (int i = 0; i < 6; i++) { Lx[3 * i] = L[10 * i]; Lx[3 * i + 1] = L[10 * i + 1]; Lx[3 * i + 2] = L[10 * i + 2]; }
+        svd_solve_ws<6, 3>(Lx, rho, bx, ws);
+        if (bx[0] < 0) { be[0] = sqrt(-bx[0]); be[1] = (bx[2] < 0) ? sqrt(-bx[2]) : 0.0; }
+        else { be[0] = sqrt(bx[0]); be[1] = (bx[2] > 0) ? sqrt(bx[2]) : 0.0; }
+        if (bx[1] < 0) be[0] = -be[0];
+        be[2] = 0.0; be[3] = 0.0;
+    } else {
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 5; j++) Lx[5 * i + j] = L[10 * i + j];
+        svd_solve_ws<6, 5>(Lx, rho, bx, ws);
+        if (bx[0] < 0) { be[0] = sqrt(-bx[0]); be[1] = (bx[2] < 0) ? sqrt(-bx[2]) : 0.0; }
+        else { be[0] = sqrt(bx[0]); be[1] = (bx[2] > 0) ? sqrt(bx[2]) : 0.0; }
+        if (bx[1] < 0) be[0] = -be[0];
+        be[2] = bx[3] / be[0];
+        be[3] = 0.0;
+    }
+    epnp_gauss_newton(L, rho, be, ws);
+    double* res = ar + EA_RES + (branch - 1) * 13;
+    res[0] = epnp_compute_R_and_t(ar, be, res + 1, res + 10, ws, fu, fv, uc, vc);
+}
+
+__global__ __launch_bounds__(EP_G * EP_HPB) void k_pnp_epnp(DevBuffers d) {
+    __shared__ double arena[EP_HPB * EP_STRIDE];
     const int seq = blockIdx.y;
     const SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= d.K) return;
-    const size_t o = (size_t)seq * d.CAP;
-    const int* idx = d.subsets + ((size_t)seq * d.K + h) * 5;
+    const int g = threadIdx.x / EP_G, q = threadIdx.x % EP_G;
+    const int h = blockIdx.x * EP_HPB + g;
+    const bool valid = h < d.K;
+    double* ar = arena + g * EP_STRIDE;
     const double fx = s.K[0], fy = s.K[4], cx = s.K[2], cy = s.K[5];
-    const double ifx = 1. / fx, ify = 1. / fy;
-    double obj[15], img[10], R[9], t[3];
-    for (int i = 0; i < 5; i++) {
-        int k = idx[i];
-        obj[3 * i] = d.world[3 * (o + k)]; obj[3 * i + 1] = d.world[3 * (o + k) + 1]; obj[3 * i + 2] = d.world[3 * (o + k) + 2];
-        float2 c = d.tl1[o + k];
-        // undistortPoints on CV_32FC2 with zero distortion (normalise in f64, store f32), then epnp re-applies fu, uc
-        float xn = (float)(((double)c.x - cx) * ifx), yn = (float)(((double)c.y - cy) * ify);
-        img[2 * i] = (double)xn * fx + cx; img[2 * i + 1] = (double)yn * fy + cy;
+    if (valid && q == 0) {
+        const size_t o = (size_t)seq * d.CAP;
+        const int* idx = d.subsets + ((size_t)seq * d.K + h) * 5;
+        const double ifx = 1. / fx, ify = 1. / fy;
+        for (int i = 0; i < 5; i++) {
+            int k = idx[i];
+            ar[EA_PWS + 3 * i] = d.world[3 * (o + k)]; ar[EA_PWS + 3 * i + 1] = d.world[3 * (o + k) + 1]; ar[EA_PWS + 3 * i + 2] = d.world[3 * (o + k) + 2];
+            float2 c = d.tl1[o + k];
+            // undistortPoints on CV_32FC2 with zero distortion (normalise in f64, store f32), then epnp re-applies fu, uc
+            float xn = (float)(((double)c.x - cx) * ifx), yn = (float)(((double)c.y - cy) * ify);
+            ar[EA_US + 2 * i] = (double)xn * fx + cx; ar[EA_US + 2 * i + 1] = (double)yn * fy + cy;
+        }
+        epnp_setup(ar, fx, fy, cx, cy);
     }
-    epnp5(obj, img, fx, fy, cx, cy, R, t);
-    double* out = d.hyp + ((size_t)seq * d.K + h) * 12;
-    for (int i = 0; i < 9; i++) out[i] = R[i];
-    for (int i = 0; i < 3; i++) out[9 + i] = t[i];
+    __syncthreads();
+    // ---- 12 x 12 one-sided Jacobi, round-robin ordering: lane q < 6 owns pair q of every round
+    bool done = !valid;
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+        for (int r = 0; r < 11; r++) {
+            if (!done && q < 6) {
+                int pa = q == 0 ? 0 : 1 + (q - 1 + r) % 11;
+                int pb = 1 + (10 - q + r) % 11;
+                int i = pa < pb ? pa : pb, j = pa < pb ? pb : pa;
+                changed |= rotate_pair12(ar + EA_AT, ar + EA_W, ar + EA_VT, i, j);
+            }
+            __syncthreads();
+        }
+        const unsigned long long m = __ballot(changed);
+        if (((m >> (g * EP_G)) & 0xFFull) == 0) done = true;            // this hypothesis converged (no pair rotated in the sweep)
+        if (__ballot(!done) == 0ull) break;
+    }
+    __syncthreads();
+    if (valid && q == 0) epnp_sort_and_L(ar);
+    __syncthreads();
+    if (valid && q < 3) epnp_branch(ar, q + 1, fx, fy, cx, cy);
+    __syncthreads();
+    if (valid && q == 0) {
+        const double* res = ar + EA_RES;
+        int N = 1;
+        if (res[13] < res[0]) N = 2;
+        if (res[26] < res[(N - 1) * 13]) N = 3;
+        const double* w = res + (N - 1) * 13;
+        double* out = d.hyp + ((size_t)seq * d.K + h) * 12;
+        for (int i = 0; i < 12; i++) out[i] = w[1 + i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ hypothesis scoring
@@ -552,7 +710,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
 
 void launch_pnp(const DevBuffers& d, hipStream_t st) {
     hipLaunchKernelGGL(k_pnp_subsets, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
-    hipLaunchKernelGGL(k_pnp_epnp, dim3((d.K + 63) / 64, d.B), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(k_pnp_epnp, dim3((d.K + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d);
     hipLaunchKernelGGL(k_pnp_score, dim3(d.K, d.B), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_pnp_final, dim3(d.B), dim3(PF_THREADS), 0, st, d);
 }

@@ -9,8 +9,15 @@
 
 // At: N rows of length M (transpose of an M x N matrix, M >= N).  On exit rows i < n1 of At hold the
 // left singular vectors, Wv[N] the singular values (descending), Vt (N x N) the right singular vectors as rows.
-template <int M, int N>
-__device__ void jacobi_svd(double* At, double* Wv, double* Vt, int n1) {
+// A strided view of per-thread data living in LDS as [element][thread]: element i of this thread is base[i * STRIDE].
+template <int STRIDE> struct LdsVec {
+    double* base;
+    __device__ __forceinline__ double& operator[](int i) const { return base[i * STRIDE]; }
+    __device__ __forceinline__ LdsVec operator+(int off) const { return LdsVec{base + off * STRIDE}; }
+};
+
+template <int M, int N, typename PA = double*, typename PW = double*>
+__device__ void jacobi_svd(PA At, PW Wv, PA Vt, int n1) {
     const double eps = SVO_DBL_EPS * 10, minval = SVO_DBL_MIN;
     const int max_iter = M > 30 ? M : 30;
     for (int i = 0; i < N; i++) {
@@ -24,7 +31,7 @@ __device__ void jacobi_svd(double* At, double* Wv, double* Vt, int n1) {
         bool changed = false;
         for (int i = 0; i < N - 1; i++)
             for (int j = i + 1; j < N; j++) {
-                double* Ai = At + i * M; double* Aj = At + j * M;
+                PA Ai = At + i * M; PA Aj = At + j * M;
                 double a = Wv[i], p = 0, b = Wv[j], c, s;
                 for (int k = 0; k < M; k++) p += Ai[k] * Aj[k];
                 if (fabs(p) <= eps * sqrt(a * b)) continue;
@@ -47,7 +54,7 @@ __device__ void jacobi_svd(double* At, double* Wv, double* Vt, int n1) {
                 }
                 Wv[i] = a; Wv[j] = b;
                 changed = true;
-                double* Vi = Vt + i * N; double* Vj = Vt + j * N;
+                PA Vi = Vt + i * N; PA Vj = Vt + j * N;
                 for (int k = 0; k < N; k++) {
                     double t0 = c * Vi[k] + s * Vj[k];
                     double t1 = -s * Vi[k] + c * Vj[k];
