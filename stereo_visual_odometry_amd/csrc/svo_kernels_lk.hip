@@ -45,21 +45,23 @@ template <int W> struct LkLayout {
     static constexpr int NB = PPL + 1;                // search-window bytes per lane per row
 };
 
-// sum over the 16 lanes of a DPP row, result in every lane of the row
-__device__ __forceinline__ int dpp_row_sum(int v) {
+// wave-wide sum of an int (each lane's |value| small enough that the 64-lane sum fits int32): 4 DPP steps inside the
+// rows of 16, row_bcast:15 / row_bcast:31 across rows, total read from lane 63 into an SGPR
+__device__ __forceinline__ int wave_sum_i32(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
     v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
     v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror: every lane holds its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
-// exact wave-wide sum of int32 partials as int64, returned in SGPRs (uniform)
-__device__ __forceinline__ long long wave_sum_i64(int partial) {
-    int lo = dpp_row_sum(partial & 0xFFFF);          // 16 x 65535 fits
-    int hi = dpp_row_sum(partial >> 16);             // arithmetic shift: signed high half
-    int slo = __builtin_amdgcn_readlane(lo, 0) + __builtin_amdgcn_readlane(lo, 16) + __builtin_amdgcn_readlane(lo, 32) + __builtin_amdgcn_readlane(lo, 48);
-    int shi = __builtin_amdgcn_readlane(hi, 0) + __builtin_amdgcn_readlane(hi, 16) + __builtin_amdgcn_readlane(hi, 32) + __builtin_amdgcn_readlane(hi, 48);
-    return (long long)shi * 65536ll + (long long)slo;
+// exact wave-wide sum of int32 partials, as the float the LK code needs: the partial is split into 16-bit halves
+// (each half-sum fits int32), and hi * 65536 + lo is formed in f64 where it is exact (|sum| < 2^53), then rounded once.
+__device__ __forceinline__ float wave_sum_to_float(int partial) {
+    const int slo = wave_sum_i32(partial & 0xFFFF);
+    const int shi = wave_sum_i32(partial >> 16);                      // arithmetic shift: signed high half
+    return (float)((double)shi * 65536.0 + (double)slo);
 }
 
 __device__ __forceinline__ void lk_weights(float a, float b, int& iw00, int& iw01, int& iw10, int& iw11) {
@@ -79,6 +81,27 @@ __device__ __forceinline__ void load_bytes(const uint8_t* __restrict__ p, int (&
     const UD u = *reinterpret_cast<const UD*>(p);
 #pragma unroll
     for (int i = 0; i < N; i++) out[i] = (int)((u.v[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+}
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+// a0*b0 + a1*b1 + acc on packed signed 16-bit pairs (v_dot2c_i32_i16)
+__device__ __forceinline__ int dot2(unsigned a, unsigned b, int acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), acc, false);
+}
+__device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
+
+// N bytes at p (any alignment) -> N-1 packed pairs: pair[x] = byte[x] | byte[x+1] << 16 (one v_perm_b32 each)
+template <int N>
+__device__ __forceinline__ void load_pairs(const uint8_t* __restrict__ p, unsigned (&pair)[N - 1]) {
+    constexpr int ND = (N + 3) / 4;
+    struct __attribute__((packed, aligned(1))) UD { unsigned v[ND]; };
+    const UD u = *reinterpret_cast<const UD*>(p);
+#pragma unroll
+    for (int x = 0; x < N - 1; x++) {
+        const int k = x >> 2, o = x & 3;
+        const unsigned lo = u.v[k], hi = (k + 1 < ND) ? u.v[k + 1] : 0u;
+        pair[x] = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (unsigned)o | ((unsigned)(o + 1) << 16));
+    }
 }
 
 // One cv::calcOpticalFlowPyrLK track of a single point across all pyramid levels (LKTrackerInvoker semantics,
@@ -147,19 +170,19 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         // ---- patch samples (kept in registers for the Newton loop) + covariance partials
         int iw00, iw01, iw10, iw11;
         lk_weights(ppx - (float)ipx, ppy - (float)ipy, iw00, iw01, iw10, iw11);
+        unsigned w0 = pack16(iw00, iw01), w1 = pack16(iw10, iw11);
         int Ir[PPL], Ixr[PPL], Iyr[PPL];
         int pA11 = 0, pA12 = 0, pA22 = 0;
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             const bool on = lane_on && (xs + j < W);
-            int ival = DESCALE(__mul24(sv[1][j + 1], iw00) + __mul24(sv[1][j + 2], iw01) + __mul24(sv[2][j + 1], iw10) + __mul24(sv[2][j + 2], iw11), LK_WBITS - 5);
-            int ixval = DESCALE(__mul24(dxv[0][j], iw00) + __mul24(dxv[0][j + 1], iw01) + __mul24(dxv[1][j], iw10) + __mul24(dxv[1][j + 1], iw11), LK_WBITS);
-            int iyval = DESCALE(__mul24(dyv[0][j], iw00) + __mul24(dyv[0][j + 1], iw01) + __mul24(dyv[1][j], iw10) + __mul24(dyv[1][j + 1], iw11), LK_WBITS);
+            int ival = dot2(pack16(sv[2][j + 1], sv[2][j + 2]), w1, dot2(pack16(sv[1][j + 1], sv[1][j + 2]), w0, 1 << (LK_WBITS - 6))) >> (LK_WBITS - 5);
+            int ixval = dot2(pack16(dxv[1][j], dxv[1][j + 1]), w1, dot2(pack16(dxv[0][j], dxv[0][j + 1]), w0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
+            int iyval = dot2(pack16(dyv[1][j], dyv[1][j + 1]), w1, dot2(pack16(dyv[0][j], dyv[0][j + 1]), w0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
             Ir[j] = on ? ival : 0; Ixr[j] = on ? ixval : 0; Iyr[j] = on ? iyval : 0;      // masked pixels contribute exact zeros
             pA11 += __mul24(Ixr[j], Ixr[j]); pA12 += __mul24(Ixr[j], Iyr[j]); pA22 += __mul24(Iyr[j], Iyr[j]);
         }
-        const long long iA11 = wave_sum_i64(pA11), iA12 = wave_sum_i64(pA12), iA22 = wave_sum_i64(pA22);
-        const float A11 = (float)(double)iA11 * FLT_SCALE, A12 = (float)(double)iA12 * FLT_SCALE, A22 = (float)(double)iA22 * FLT_SCALE;
+        const float A11 = wave_sum_to_float(pA11) * FLT_SCALE, A12 = wave_sum_to_float(pA12) * FLT_SCALE, A22 = wave_sum_to_float(pA22) * FLT_SCALE;
         float Dt = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * W * W);
         if ((double)minEig < crit.min_eig || Dt < 1.1920928955078125e-07f) {
@@ -169,49 +192,56 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         Dt = 1.f / Dt;
         nx -= half; ny -= half;
         float pdx = 0.f, pdy = 0.f;
-        int jw[2][NB];                               // search window bytes, valid for integer origin (cinx, ciny)
-        int cinx = 0x7fffffff, ciny = 0x7fffffff;
-        for (int j = 0; j < crit.max_count; j++) {
+        // Newton iterations, organised in epochs of constant INTEGER window origin: the search window (two rows of
+        // packed byte pairs per lane) is loaded at the start of an epoch and stays in registers until floor(n) changes.
+        int j = 0;
+        bool stop = crit.max_count <= 0;
+        while (!stop) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
             if (inx < -W || inx >= L.w || iny < -W || iny >= L.h) {
                 if (level == 0) status = 0;
                 break;
             }
-            if (inx != cinx || iny != ciny) {        // the integer window moved: reload it (uniform branch)
-                cinx = inx; ciny = iny;
-                if (inx >= 0 && inx + EXT < L.w && iny >= 0 && iny + W < L.h) {
-                    const uint8_t* p = Bm + (size_t)(iny + row) * L.w + (inx + xs);
-                    load_bytes<NB>(p, jw[0]);
-                    load_bytes<NB>(p + L.w, jw[1]);
-                } else {
+            unsigned P0[PPL], P1[PPL];
+            if (inx >= 0 && inx + EXT < L.w && iny >= 0 && iny + W < L.h) {
+                const uint8_t* p = Bm + (size_t)(iny + row) * L.w + (inx + xs);
+                load_pairs<NB>(p, P0);
+                load_pairs<NB>(p + L.w, P1);
+            } else {
+                int jb[2][NB];
 #pragma unroll
-                    for (int r = 0; r < 2; r++) {
-                        const uint8_t* rp = Bm + (size_t)reflect101(iny + row + r, L.h) * L.w;
+                for (int r = 0; r < 2; r++) {
+                    const uint8_t* rp = Bm + (size_t)reflect101(iny + row + r, L.h) * L.w;
 #pragma unroll
-                        for (int c = 0; c < NB; c++) jw[r][c] = rp[reflect101(inx + xs + c, L.w)];
-                    }
+                    for (int c = 0; c < NB; c++) jb[r][c] = rp[reflect101(inx + xs + c, L.w)];
                 }
-            }
-            lk_weights(nx - (float)inx, ny - (float)iny, iw00, iw01, iw10, iw11);
-            int pb1 = 0, pb2 = 0;
 #pragma unroll
-            for (int jj = 0; jj < PPL; jj++) {
-                int v = DESCALE(__mul24(jw[0][jj], iw00) + __mul24(jw[0][jj + 1], iw01) + __mul24(jw[1][jj], iw10) + __mul24(jw[1][jj + 1], iw11), LK_WBITS - 5);
-                // masked pixels have Ix = Iy = 0, so whatever diff they see contributes an exact zero
-                int diff = v - Ir[jj];
-                pb1 += __mul24(diff, Ixr[jj]); pb2 += __mul24(diff, Iyr[jj]);
+                for (int c = 0; c < PPL; c++) { P0[c] = pack16(jb[0][c], jb[0][c + 1]); P1[c] = pack16(jb[1][c], jb[1][c + 1]); }
             }
-            const long long ib1 = wave_sum_i64(pb1), ib2 = wave_sum_i64(pb2);
-            const float b1 = (float)(double)ib1 * FLT_SCALE, b2 = (float)(double)ib2 * FLT_SCALE;
-            const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
-            nx += dx; ny += dy;
-            outx = nx + half; outy = ny + half;
-            if ((double)dx * (double)dx + (double)dy * (double)dy <= crit.eps2) break;
-            if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
-                outx -= dx * 0.5f; outy -= dy * 0.5f;
-                break;
+            const float fx0 = (float)inx, fy0 = (float)iny;
+            for (;;) {
+                lk_weights(nx - fx0, ny - fy0, iw00, iw01, iw10, iw11);
+                w0 = pack16(iw00, iw01); w1 = pack16(iw10, iw11);
+                int pb1 = 0, pb2 = 0;
+#pragma unroll
+                for (int jj = 0; jj < PPL; jj++) {
+                    // masked pixels have Ix = Iy = 0, so whatever diff they see contributes an exact zero
+                    int diff = (dot2(P1[jj], w1, dot2(P0[jj], w0, 1 << (LK_WBITS - 6))) >> (LK_WBITS - 5)) - Ir[jj];
+                    pb1 += __mul24(diff, Ixr[jj]); pb2 += __mul24(diff, Iyr[jj]);
+                }
+                const float b1 = wave_sum_to_float(pb1) * FLT_SCALE, b2 = wave_sum_to_float(pb2) * FLT_SCALE;
+                const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
+                nx += dx; ny += dy;
+                outx = nx + half; outy = ny + half;
+                if ((double)dx * (double)dx + (double)dy * (double)dy <= crit.eps2) { stop = true; break; }
+                if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+                    outx -= dx * 0.5f; outy -= dy * 0.5f;
+                    stop = true; break;
+                }
+                pdx = dx; pdy = dy;
+                if (++j >= crit.max_count) { stop = true; break; }
+                if ((int)floorf(nx) != inx || (int)floorf(ny) != iny) break;       // integer origin moved: new epoch
             }
-            pdx = dx; pdy = dy;
         }
         // flags = 0 with err != NULL (vo.cpp:182,203): the level-0 error block re-checks the final window origin
         if (status && level == 0) {
