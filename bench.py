@@ -45,11 +45,11 @@ def algorithmic_bytes(W, H, N, win, max_level, K, r=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--seqs", type=int, default=32, help="independent stereo sequences batched per GPU")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--seqs", type=int, default=128, help="independent stereo sequences batched per GPU")
     ap.add_argument("--depth", type=int, default=4, help="frames kept in flight per context (<= 8)")
-    ap.add_argument("--contexts", type=int, default=4, help="sequence groups per GPU, each on its own HIP stream (their kernels overlap)")
+    ap.add_argument("--contexts", type=int, default=2, help="sequence groups per GPU, each on its own HIP stream (their kernels overlap)")
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic sequences rendered per rank")
     ap.add_argument("--frames", type=int, default=10, help="frames rendered per pool sequence (ping-pong replay)")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
