@@ -28,3 +28,14 @@ def test_reference_run_tests_through_facade():
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ALL TESTS PASS" in out.stdout
+
+
+def test_stereo_synchronizer_host_logic():
+    """ROS-callback-shaped adapter (include/svo/stereo_sync.hpp): pairing + bounded queues; no GPU needed."""
+    exe = os.path.join(ROOT, "tests", "cpp", "sync_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "sync_test.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "stereo_visual_odometry_amd"), "-lsvo_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "stereo_visual_odometry_amd")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "SYNC OK" in out.stdout, out.stdout + out.stderr
