@@ -57,11 +57,12 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 // exact wave-wide sum of int32 partials, as the float the LK code needs: the partial is split into 16-bit halves
-// (each half-sum fits int32), and hi * 65536 + lo is formed in f64 where it is exact (|sum| < 2^53), then rounded once.
+// (each half-sum fits 23 bits).  (float)hi and (float)lo are exact, (float)hi * 65536 is exact (power of two), so the
+// single f32 addition rounds the exact integer sum once, to nearest-even — the same value as (float)(double)(int64 sum).
 __device__ __forceinline__ float wave_sum_to_float(int partial) {
     const int slo = wave_sum_i32(partial & 0xFFFF);
     const int shi = wave_sum_i32(partial >> 16);                      // arithmetic shift: signed high half
-    return (float)((double)shi * 65536.0 + (double)slo);
+    return (float)shi * 65536.f + (float)slo;
 }
 
 __device__ __forceinline__ void lk_weights(float a, float b, int& iw00, int& iw01, int& iw10, int& iw11) {
@@ -84,6 +85,7 @@ __device__ __forceinline__ void load_bytes(const uint8_t* __restrict__ p, int (&
 }
 
 typedef short short2v __attribute__((ext_vector_type(2)));
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 // a0*b0 + a1*b1 + acc on packed signed 16-bit pairs (v_dot2c_i32_i16)
 __device__ __forceinline__ int dot2(unsigned a, unsigned b, int acc) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), acc, false);
@@ -136,50 +138,80 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             if (level == 0) status = 0;
             continue;
         }
-        // ---- template rows: 4 x NS source bytes per lane, origin (ipx-1+xs, ipy-1+row); REFLECT_101 = the pyramid border
-        int sv[4][NS];
+        // ---- template: 4 rows x NS source bytes per lane, origin (ipx-1+xs, ipy-1+row); REFLECT_101 = the pyramid border.
+        // Everything is kept as packed 16-bit PAIRS (value[c], value[c+1]) — the operand layout of v_dot2c_i32_i16 —
+        // and the Scharr derivatives are computed with packed 16-bit math directly on those pairs:
+        //   t0(c) = 3*(s[y-1][c] + s[y+1][c]) + 10*s[y][c]      t1(c) = s[y+1][c] - s[y-1][c]
+        //   dx(c) = t0(c+1) - t0(c-1)                            dy(c) = 3*(t1(c-1) + t1(c+1)) + 10*t1(c)
+        // (all intermediates fit 16 bits: |t0| <= 4080, |dx|, |dy| <= 4080).
+        unsigned Ip[2][PPL], DXp[2][PPL], DYp[2][PPL];             // [row 0/1 of the bilinear][pixel]: packed pairs
         const bool interior = ipx >= 1 && ipx + EXT + 1 < L.w && ipy >= 1 && ipy + W + 1 < L.h;
         if (interior) {
+            unsigned Q[4][NS - 1];
             const uint8_t* p = A + (size_t)(ipy - 1 + row) * L.w + (ipx - 1 + xs);
 #pragma unroll
-            for (int r = 0; r < 4; r++) load_bytes<NS>(p + (size_t)r * L.w, sv[r]);
+            for (int r = 0; r < 4; r++) load_pairs<NS>(p + (size_t)r * L.w, Q[r]);
+#pragma unroll
+            for (int yy = 0; yy < 2; yy++) {
+                ushort2v T0[NS - 1]; short2v T1[NS - 1];
+#pragma unroll
+                for (int c = 0; c < NS - 1; c++) {
+                    const ushort2v q0 = __builtin_bit_cast(ushort2v, Q[yy][c]), q1 = __builtin_bit_cast(ushort2v, Q[yy + 1][c]), q2 = __builtin_bit_cast(ushort2v, Q[yy + 2][c]);
+                    T0[c] = (q0 + q2) * (unsigned short)3 + q1 * (unsigned short)10;
+                    T1[c] = __builtin_bit_cast(short2v, (ushort2v)(q2 - q0));
+                }
+#pragma unroll
+                for (int x = 0; x < PPL; x++) {
+                    DXp[yy][x] = __builtin_bit_cast(unsigned, (ushort2v)(T0[x + 2] - T0[x]));
+                    DYp[yy][x] = __builtin_bit_cast(unsigned, (short2v)((T1[x] + T1[x + 2]) * (short)3 + T1[x + 1] * (short)10));
+                    Ip[yy][x] = Q[yy + 1][x + 1];
+                }
+            }
         } else {
+            int sv[4][NS];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const uint8_t* rp = A + (size_t)reflect101(ipy - 1 + row + r, L.h) * L.w;
 #pragma unroll
                 for (int c = 0; c < NS; c++) sv[r][c] = rp[reflect101(ipx - 1 + xs + c, L.w)];
             }
-        }
-        // ---- Scharr derivatives at the 2 x (PPL+1) grid points this lane interpolates from; 0 outside the image
-        int dxv[2][NB], dyv[2][NB];
+            int dxv[2][NB], dyv[2][NB];
 #pragma unroll
-        for (int yy = 0; yy < 2; yy++)
+            for (int yy = 0; yy < 2; yy++)
 #pragma unroll
-            for (int xx = 0; xx < NB; xx++) {
-                int t0m = 3 * (sv[yy][xx] + sv[yy + 2][xx]) + 10 * sv[yy + 1][xx];
-                int t0p = 3 * (sv[yy][xx + 2] + sv[yy + 2][xx + 2]) + 10 * sv[yy + 1][xx + 2];
-                int t1m = sv[yy + 2][xx] - sv[yy][xx], t1c = sv[yy + 2][xx + 1] - sv[yy][xx + 1], t1p = sv[yy + 2][xx + 2] - sv[yy][xx + 2];
-                int a = t0p - t0m, b = 3 * (t1m + t1p) + 10 * t1c;
-                if (!interior) {
+                for (int xx = 0; xx < NB; xx++) {
+                    int t0m = 3 * (sv[yy][xx] + sv[yy + 2][xx]) + 10 * sv[yy + 1][xx];
+                    int t0p = 3 * (sv[yy][xx + 2] + sv[yy + 2][xx + 2]) + 10 * sv[yy + 1][xx + 2];
+                    int t1m = sv[yy + 2][xx] - sv[yy][xx], t1c = sv[yy + 2][xx + 1] - sv[yy][xx + 1], t1p = sv[yy + 2][xx + 2] - sv[yy][xx + 2];
+                    int da = t0p - t0m, db = 3 * (t1m + t1p) + 10 * t1c;
                     int gx = ipx + xs + xx, gy = ipy + row + yy;
-                    if (gx < 0 || gx >= L.w || gy < 0 || gy >= L.h) { a = 0; b = 0; }
+                    if (gx < 0 || gx >= L.w || gy < 0 || gy >= L.h) { da = 0; db = 0; }     // derivBorder = CONSTANT 0
+                    dxv[yy][xx] = da; dyv[yy][xx] = db;
                 }
-                dxv[yy][xx] = a; dyv[yy][xx] = b;
-            }
+#pragma unroll
+            for (int yy = 0; yy < 2; yy++)
+#pragma unroll
+                for (int x = 0; x < PPL; x++) {
+                    DXp[yy][x] = pack16(dxv[yy][x], dxv[yy][x + 1]);
+                    DYp[yy][x] = pack16(dyv[yy][x], dyv[yy][x + 1]);
+                    Ip[yy][x] = pack16(sv[yy + 1][x + 1], sv[yy + 1][x + 2]);
+                }
+        }
         // ---- patch samples (kept in registers for the Newton loop) + covariance partials
         int iw00, iw01, iw10, iw11;
         lk_weights(ppx - (float)ipx, ppy - (float)ipy, iw00, iw01, iw10, iw11);
         unsigned w0 = pack16(iw00, iw01), w1 = pack16(iw10, iw11);
+        // lanes / pixels outside the window get zero derivative weights: their Ix = Iy = 0, so they contribute exact zeros
+        const unsigned wd0 = lane_on ? w0 : 0u, wd1 = lane_on ? w1 : 0u;
         int Ir[PPL], Ixr[PPL], Iyr[PPL];
         int pA11 = 0, pA12 = 0, pA22 = 0;
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
-            const bool on = lane_on && (xs + j < W);
-            int ival = dot2(pack16(sv[2][j + 1], sv[2][j + 2]), w1, dot2(pack16(sv[1][j + 1], sv[1][j + 2]), w0, 1 << (LK_WBITS - 6))) >> (LK_WBITS - 5);
-            int ixval = dot2(pack16(dxv[1][j], dxv[1][j + 1]), w1, dot2(pack16(dxv[0][j], dxv[0][j + 1]), w0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
-            int iyval = dot2(pack16(dyv[1][j], dyv[1][j + 1]), w1, dot2(pack16(dyv[0][j], dyv[0][j + 1]), w0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
-            Ir[j] = on ? ival : 0; Ixr[j] = on ? ixval : 0; Iyr[j] = on ? iyval : 0;      // masked pixels contribute exact zeros
+            const bool on = (EXT == W) || (xs + j < W);
+            Ir[j] = dot2(Ip[1][j], w1, dot2(Ip[0][j], w0, 1 << (LK_WBITS - 6))) >> (LK_WBITS - 5);
+            int ixval = dot2(DXp[1][j], wd1, dot2(DXp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
+            int iyval = dot2(DYp[1][j], wd1, dot2(DYp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
+            Ixr[j] = on ? ixval : 0; Iyr[j] = on ? iyval : 0;
             pA11 += __mul24(Ixr[j], Ixr[j]); pA12 += __mul24(Ixr[j], Iyr[j]); pA22 += __mul24(Iyr[j], Iyr[j]);
         }
         const float A11 = wave_sum_to_float(pA11) * FLT_SCALE, A12 = wave_sum_to_float(pA12) * FLT_SCALE, A22 = wave_sum_to_float(pA22) * FLT_SCALE;
@@ -234,7 +266,9 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 nx += dx; ny += dy;
                 outx = nx + half; outy = ny + half;
                 if ((double)dx * (double)dx + (double)dy * (double)dy <= crit.eps2) { stop = true; break; }
-                if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+                // "(double)|v| < 0.01" for a float v is exactly "|v| < nextafterf((float)0.01)": 0.01 lies between the floats
+                // 0x3C23D70A and 0x3C23D70B, so v < 0.01 (as doubles) <=> v <= 0x3C23D70A <=> v < 0x3C23D70B
+                if (j > 0 && fabsf(dx + pdx) < 0.010000000707805157f && fabsf(dy + pdy) < 0.010000000707805157f) {
                     outx -= dx * 0.5f; outy -= dy * 0.5f;
                     stop = true; break;
                 }
