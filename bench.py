@@ -73,7 +73,8 @@ def main():
     # ---- workload: BASELINE.json configs[1] — KITTI-00 shaped 1241x376, ~2000 FAST features, LK 21x21, maxLevel 3
     cal = syn.KITTI00
     W, H = cal["width"], cal["height"]
-    over = dict(win_w=21, win_h=21, max_level=3, ransac_iterations=100, max_translation_norm=2.0)
+    win = int(os.environ.get("SVO_BENCH_WIN", "21"))
+    over = dict(win_w=win, win_h=win, max_level=3, ransac_iterations=100, max_translation_norm=2.0)
     B, F = args.seqs, args.frames
     pool = [syn.StereoSequence(cal=cal, n_frames=F, seed=0x5EED0002 + 97 * rank + g, step=0.5, cell_px=17.6)
             for g in range(args.pool)]

@@ -33,35 +33,48 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 
-template <int W> struct LkLayout {
-    static constexpr int ppl() {                 // pixels per lane: smallest p with W * ceil(W/p) <= 64
+// G lanes cooperate on one feature (G = 16: one DPP row per feature, 4 features per wave; G = 64: the whole wave).
+// The window is cut into NSEG = W * LPR row segments of PPL pixels; each lane owns SPL consecutive segments.
+template <int W, int G> struct LkLayout {
+    static constexpr int ppl() {                 // pixels per segment: smallest p with W * ceil(W/p) <= 64
         for (int p = 1; p <= W; p++) if (W * ((W + p - 1) / p) <= 64) return p;
         return W;
     }
     static constexpr int PPL = ppl();
-    static constexpr int LPR = (W + PPL - 1) / PPL;   // lanes per window row
-    static constexpr int EXT = LPR * PPL;             // columns covered by the lanes of a row (>= W)
-    static constexpr int NS = PPL + 3;                // template source bytes per lane per row
-    static constexpr int NB = PPL + 1;                // search-window bytes per lane per row
+    static constexpr int LPR = (W + PPL - 1) / PPL;   // segments per window row
+    static constexpr int EXT = LPR * PPL;             // columns covered by the segments of a row (>= W)
+    static constexpr int NSEG = W * LPR;
+    static constexpr int SPL = (NSEG + G - 1) / G;    // segments per lane
+    static constexpr int NS = PPL + 3;                // template source bytes per segment per row
+    static constexpr int NB = PPL + 1;                // search-window bytes per segment per row
 };
 
-// wave-wide sum of an int (each lane's |value| small enough that the 64-lane sum fits int32): 4 DPP steps inside the
-// rows of 16, row_bcast:15 / row_bcast:31 across rows, total read from lane 63 into an SGPR
-__device__ __forceinline__ int wave_sum_i32(int v) {
+// sum over the G lanes of a feature group; every lane of the group receives the total
+template <int G>
+__device__ __forceinline__ int group_sum_i32(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
     v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
     v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
     v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror: every lane holds its row's sum
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
-    return __builtin_amdgcn_readlane(v, 63);
+    if (G == 64) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+        v = __builtin_amdgcn_readlane(v, 63);
+    }
+    if (G == 32) {                                                       // two rows per feature: add the partner row's sum
+        const int r0 = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16);
+        const int r1 = __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+        v = (threadIdx.x & 32) ? r1 : r0;
+    }
+    return v;
 }
-// exact wave-wide sum of int32 partials, as the float the LK code needs: the partial is split into 16-bit halves
+// exact group-wide sum of int32 partials, as the float the LK code needs: the partial is split into 16-bit halves
 // (each half-sum fits 23 bits).  (float)hi and (float)lo are exact, (float)hi * 65536 is exact (power of two), so the
 // single f32 addition rounds the exact integer sum once, to nearest-even — the same value as (float)(double)(int64 sum).
-__device__ __forceinline__ float wave_sum_to_float(int partial) {
-    const int slo = wave_sum_i32(partial & 0xFFFF);
-    const int shi = wave_sum_i32(partial >> 16);                      // arithmetic shift: signed high half
+template <int G>
+__device__ __forceinline__ float group_sum_to_float(int partial) {
+    const int slo = group_sum_i32<G>(partial & 0xFFFF);
+    const int shi = group_sum_i32<G>(partial >> 16);                  // arithmetic shift: signed high half
     return (float)shi * 65536.f + (float)slo;
 }
 
@@ -73,16 +86,7 @@ __device__ __forceinline__ void lk_weights(float a, float b, int& iw00, int& iw0
 }
 
 struct LkCrit { int max_count; double eps2; double min_eig; };
-
-// N bytes starting at p (any alignment) into out[0..N): unaligned dword loads + byte extraction
-template <int N>
-__device__ __forceinline__ void load_bytes(const uint8_t* __restrict__ p, int (&out)[N]) {
-    constexpr int ND = (N + 3) / 4;
-    struct __attribute__((packed, aligned(1))) UD { unsigned v[ND]; };
-    const UD u = *reinterpret_cast<const UD*>(p);
-#pragma unroll
-    for (int i = 0; i < N; i++) out[i] = (int)((u.v[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-}
+template <int SPL> struct LkSegs { int row[SPL]; int xs[SPL]; bool on[SPL]; };   // the window segments a lane owns
 
 typedef short short2v __attribute__((ext_vector_type(2)));
 typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
@@ -107,17 +111,15 @@ __device__ __forceinline__ void load_pairs(const uint8_t* __restrict__ p, unsign
 }
 
 // One cv::calcOpticalFlowPyrLK track of a single point across all pyramid levels (LKTrackerInvoker semantics,
-// SURVEY.md Appendix A.3).  (px,py) -> (outx,outy), status.  All 64 lanes call this together; px, py uniform.
-template <int W>
+// SURVEY.md Appendix A.3).  (px,py) -> (outx,outy), status.  Written as plain SIMT code: every "per feature" quantity
+// lives in a VGPR and is identical across the G lanes of the feature's group; control flow diverges between groups and
+// is handled by the exec mask.  segrow / segxs / segon describe the SPL window segments this lane owns.
+template <int W, int G>
 __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB,
-                        float px, float py, float& outx, float& outy, int& status, const LkCrit& crit) {
-    using LL = LkLayout<W>;
-    constexpr int PPL = LL::PPL, LPR = LL::LPR, EXT = LL::EXT, NS = LL::NS, NB = LL::NB;
-    const int lane = threadIdx.x;
-    const int row_raw = lane / LPR, seg = lane - row_raw * LPR;
-    const bool lane_on = row_raw < W;
-    const int row = lane_on ? row_raw : 0;           // idle lanes shadow row 0 so their loads stay in bounds
-    const int xs = seg * PPL;
+                        float px, float py, float& outx, float& outy, int& status, const LkCrit& crit,
+                        const LkSegs<LkLayout<W, G>::SPL>& sg) {
+    using LL = LkLayout<W, G>;
+    constexpr int PPL = LL::PPL, EXT = LL::EXT, NS = LL::NS, NB = LL::NB, SPL = LL::SPL;
     const float half = (W - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
     const int top = g.nlevels - 1;
@@ -138,83 +140,87 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             if (level == 0) status = 0;
             continue;
         }
-        // ---- template: 4 rows x NS source bytes per lane, origin (ipx-1+xs, ipy-1+row); REFLECT_101 = the pyramid border.
+        int iw00, iw01, iw10, iw11;
+        lk_weights(ppx - (float)ipx, ppy - (float)ipy, iw00, iw01, iw10, iw11);
+        unsigned w0 = pack16(iw00, iw01), w1 = pack16(iw10, iw11);
+        // ---- template: per segment 4 rows x NS source bytes, origin (ipx-1+xs, ipy-1+row); REFLECT_101 = the pyramid border.
         // Everything is kept as packed 16-bit PAIRS (value[c], value[c+1]) — the operand layout of v_dot2c_i32_i16 —
         // and the Scharr derivatives are computed with packed 16-bit math directly on those pairs:
         //   t0(c) = 3*(s[y-1][c] + s[y+1][c]) + 10*s[y][c]      t1(c) = s[y+1][c] - s[y-1][c]
         //   dx(c) = t0(c+1) - t0(c-1)                            dy(c) = 3*(t1(c-1) + t1(c+1)) + 10*t1(c)
         // (all intermediates fit 16 bits: |t0| <= 4080, |dx|, |dy| <= 4080).
-        unsigned Ip[2][PPL], DXp[2][PPL], DYp[2][PPL];             // [row 0/1 of the bilinear][pixel]: packed pairs
-        const bool interior = ipx >= 1 && ipx + EXT + 1 < L.w && ipy >= 1 && ipy + W + 1 < L.h;
-        if (interior) {
-            unsigned Q[4][NS - 1];
-            const uint8_t* p = A + (size_t)(ipy - 1 + row) * L.w + (ipx - 1 + xs);
-#pragma unroll
-            for (int r = 0; r < 4; r++) load_pairs<NS>(p + (size_t)r * L.w, Q[r]);
-#pragma unroll
-            for (int yy = 0; yy < 2; yy++) {
-                ushort2v T0[NS - 1]; short2v T1[NS - 1];
-#pragma unroll
-                for (int c = 0; c < NS - 1; c++) {
-                    const ushort2v q0 = __builtin_bit_cast(ushort2v, Q[yy][c]), q1 = __builtin_bit_cast(ushort2v, Q[yy + 1][c]), q2 = __builtin_bit_cast(ushort2v, Q[yy + 2][c]);
-                    T0[c] = (q0 + q2) * (unsigned short)3 + q1 * (unsigned short)10;
-                    T1[c] = __builtin_bit_cast(short2v, (ushort2v)(q2 - q0));
-                }
-#pragma unroll
-                for (int x = 0; x < PPL; x++) {
-                    DXp[yy][x] = __builtin_bit_cast(unsigned, (ushort2v)(T0[x + 2] - T0[x]));
-                    DYp[yy][x] = __builtin_bit_cast(unsigned, (short2v)((T1[x] + T1[x + 2]) * (short)3 + T1[x + 1] * (short)10));
-                    Ip[yy][x] = Q[yy + 1][x + 1];
-                }
-            }
-        } else {
-            int sv[4][NS];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint8_t* rp = A + (size_t)reflect101(ipy - 1 + row + r, L.h) * L.w;
-#pragma unroll
-                for (int c = 0; c < NS; c++) sv[r][c] = rp[reflect101(ipx - 1 + xs + c, L.w)];
-            }
-            int dxv[2][NB], dyv[2][NB];
-#pragma unroll
-            for (int yy = 0; yy < 2; yy++)
-#pragma unroll
-                for (int xx = 0; xx < NB; xx++) {
-                    int t0m = 3 * (sv[yy][xx] + sv[yy + 2][xx]) + 10 * sv[yy + 1][xx];
-                    int t0p = 3 * (sv[yy][xx + 2] + sv[yy + 2][xx + 2]) + 10 * sv[yy + 1][xx + 2];
-                    int t1m = sv[yy + 2][xx] - sv[yy][xx], t1c = sv[yy + 2][xx + 1] - sv[yy][xx + 1], t1p = sv[yy + 2][xx + 2] - sv[yy][xx + 2];
-                    int da = t0p - t0m, db = 3 * (t1m + t1p) + 10 * t1c;
-                    int gx = ipx + xs + xx, gy = ipy + row + yy;
-                    if (gx < 0 || gx >= L.w || gy < 0 || gy >= L.h) { da = 0; db = 0; }     // derivBorder = CONSTANT 0
-                    dxv[yy][xx] = da; dyv[yy][xx] = db;
-                }
-#pragma unroll
-            for (int yy = 0; yy < 2; yy++)
-#pragma unroll
-                for (int x = 0; x < PPL; x++) {
-                    DXp[yy][x] = pack16(dxv[yy][x], dxv[yy][x + 1]);
-                    DYp[yy][x] = pack16(dyv[yy][x], dyv[yy][x + 1]);
-                    Ip[yy][x] = pack16(sv[yy + 1][x + 1], sv[yy + 1][x + 2]);
-                }
-        }
-        // ---- patch samples (kept in registers for the Newton loop) + covariance partials
-        int iw00, iw01, iw10, iw11;
-        lk_weights(ppx - (float)ipx, ppy - (float)ipy, iw00, iw01, iw10, iw11);
-        unsigned w0 = pack16(iw00, iw01), w1 = pack16(iw10, iw11);
-        // lanes / pixels outside the window get zero derivative weights: their Ix = Iy = 0, so they contribute exact zeros
-        const unsigned wd0 = lane_on ? w0 : 0u, wd1 = lane_on ? w1 : 0u;
-        int Ir[PPL], Ixr[PPL], Iyr[PPL];
+        int Ir[SPL][PPL], Ixr[SPL][PPL], Iyr[SPL][PPL];
         int pA11 = 0, pA12 = 0, pA22 = 0;
+        const bool interior = ipx >= 1 && ipx + EXT + 1 < L.w && ipy >= 1 && ipy + W + 1 < L.h;
 #pragma unroll
-        for (int j = 0; j < PPL; j++) {
-            const bool on = (EXT == W) || (xs + j < W);
-            Ir[j] = dot2(Ip[1][j], w1, dot2(Ip[0][j], w0, 1 << (LK_WBITS - 6))) >> (LK_WBITS - 5);
-            int ixval = dot2(DXp[1][j], wd1, dot2(DXp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
-            int iyval = dot2(DYp[1][j], wd1, dot2(DYp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
-            Ixr[j] = on ? ixval : 0; Iyr[j] = on ? iyval : 0;
-            pA11 += __mul24(Ixr[j], Ixr[j]); pA12 += __mul24(Ixr[j], Iyr[j]); pA22 += __mul24(Iyr[j], Iyr[j]);
+        for (int k = 0; k < SPL; k++) {
+            const int row = sg.row[k], xs = sg.xs[k];
+            unsigned Ip[2][PPL], DXp[2][PPL], DYp[2][PPL];             // [row 0/1 of the bilinear][pixel]: packed pairs
+            if (interior) {
+                unsigned Q[4][NS - 1];
+                const uint8_t* p = A + (size_t)(ipy - 1 + row) * L.w + (ipx - 1 + xs);
+#pragma unroll
+                for (int r = 0; r < 4; r++) load_pairs<NS>(p + (size_t)r * L.w, Q[r]);
+#pragma unroll
+                for (int yy = 0; yy < 2; yy++) {
+                    ushort2v T0[NS - 1]; short2v T1[NS - 1];
+#pragma unroll
+                    for (int c = 0; c < NS - 1; c++) {
+                        const ushort2v q0 = __builtin_bit_cast(ushort2v, Q[yy][c]), q1 = __builtin_bit_cast(ushort2v, Q[yy + 1][c]), q2 = __builtin_bit_cast(ushort2v, Q[yy + 2][c]);
+                        T0[c] = (q0 + q2) * (unsigned short)3 + q1 * (unsigned short)10;
+                        T1[c] = __builtin_bit_cast(short2v, (ushort2v)(q2 - q0));
+                    }
+#pragma unroll
+                    for (int x = 0; x < PPL; x++) {
+                        DXp[yy][x] = __builtin_bit_cast(unsigned, (ushort2v)(T0[x + 2] - T0[x]));
+                        DYp[yy][x] = __builtin_bit_cast(unsigned, (short2v)((T1[x] + T1[x + 2]) * (short)3 + T1[x + 1] * (short)10));
+                        Ip[yy][x] = Q[yy + 1][x + 1];
+                    }
+                }
+            } else {
+                int sv[4][NS];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint8_t* rp = A + (size_t)reflect101(ipy - 1 + row + r, L.h) * L.w;
+#pragma unroll
+                    for (int c = 0; c < NS; c++) sv[r][c] = rp[reflect101(ipx - 1 + xs + c, L.w)];
+                }
+                int dxv[2][NB], dyv[2][NB];
+#pragma unroll
+                for (int yy = 0; yy < 2; yy++)
+#pragma unroll
+                    for (int xx = 0; xx < NB; xx++) {
+                        int t0m = 3 * (sv[yy][xx] + sv[yy + 2][xx]) + 10 * sv[yy + 1][xx];
+                        int t0p = 3 * (sv[yy][xx + 2] + sv[yy + 2][xx + 2]) + 10 * sv[yy + 1][xx + 2];
+                        int t1m = sv[yy + 2][xx] - sv[yy][xx], t1c = sv[yy + 2][xx + 1] - sv[yy][xx + 1], t1p = sv[yy + 2][xx + 2] - sv[yy][xx + 2];
+                        int da = t0p - t0m, db = 3 * (t1m + t1p) + 10 * t1c;
+                        int gx = ipx + xs + xx, gy = ipy + row + yy;
+                        if (gx < 0 || gx >= L.w || gy < 0 || gy >= L.h) { da = 0; db = 0; }     // derivBorder = CONSTANT 0
+                        dxv[yy][xx] = da; dyv[yy][xx] = db;
+                    }
+#pragma unroll
+                for (int yy = 0; yy < 2; yy++)
+#pragma unroll
+                    for (int x = 0; x < PPL; x++) {
+                        DXp[yy][x] = pack16(dxv[yy][x], dxv[yy][x + 1]);
+                        DYp[yy][x] = pack16(dyv[yy][x], dyv[yy][x + 1]);
+                        Ip[yy][x] = pack16(sv[yy + 1][x + 1], sv[yy + 1][x + 2]);
+                    }
+            }
+            // patch samples (kept in registers for the Newton loop) + covariance partials.  Segments / pixels outside
+            // the window get zero derivative weights: their Ix = Iy = 0, so they contribute exact zeros everywhere.
+            const unsigned wd0 = sg.on[k] ? w0 : 0u, wd1 = sg.on[k] ? w1 : 0u;
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const bool on = (EXT == W) || (xs + j < W);
+                Ir[k][j] = dot2(Ip[1][j], w1, dot2(Ip[0][j], w0, 1 << (LK_WBITS - 6))) >> (LK_WBITS - 5);
+                int ixval = dot2(DXp[1][j], wd1, dot2(DXp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
+                int iyval = dot2(DYp[1][j], wd1, dot2(DYp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
+                Ixr[k][j] = on ? ixval : 0; Iyr[k][j] = on ? iyval : 0;
+                pA11 += __mul24(Ixr[k][j], Ixr[k][j]); pA12 += __mul24(Ixr[k][j], Iyr[k][j]); pA22 += __mul24(Iyr[k][j], Iyr[k][j]);
+            }
         }
-        const float A11 = wave_sum_to_float(pA11) * FLT_SCALE, A12 = wave_sum_to_float(pA12) * FLT_SCALE, A22 = wave_sum_to_float(pA22) * FLT_SCALE;
+        const float A11 = group_sum_to_float<G>(pA11) * FLT_SCALE, A12 = group_sum_to_float<G>(pA12) * FLT_SCALE, A22 = group_sum_to_float<G>(pA22) * FLT_SCALE;
         float Dt = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * W * W);
         if ((double)minEig < crit.min_eig || Dt < 1.1920928955078125e-07f) {
@@ -225,7 +231,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         nx -= half; ny -= half;
         float pdx = 0.f, pdy = 0.f;
         // Newton iterations, organised in epochs of constant INTEGER window origin: the search window (two rows of
-        // packed byte pairs per lane) is loaded at the start of an epoch and stays in registers until floor(n) changes.
+        // packed byte pairs per segment) is loaded at the start of an epoch and stays in registers until floor(n) changes.
         int j = 0;
         bool stop = crit.max_count <= 0;
         while (!stop) {
@@ -234,21 +240,27 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 if (level == 0) status = 0;
                 break;
             }
-            unsigned P0[PPL], P1[PPL];
+            unsigned P0[SPL][PPL], P1[SPL][PPL];
             if (inx >= 0 && inx + EXT < L.w && iny >= 0 && iny + W < L.h) {
-                const uint8_t* p = Bm + (size_t)(iny + row) * L.w + (inx + xs);
-                load_pairs<NB>(p, P0);
-                load_pairs<NB>(p + L.w, P1);
-            } else {
-                int jb[2][NB];
 #pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const uint8_t* rp = Bm + (size_t)reflect101(iny + row + r, L.h) * L.w;
-#pragma unroll
-                    for (int c = 0; c < NB; c++) jb[r][c] = rp[reflect101(inx + xs + c, L.w)];
+                for (int k = 0; k < SPL; k++) {
+                    const uint8_t* p = Bm + (size_t)(iny + sg.row[k]) * L.w + (inx + sg.xs[k]);
+                    load_pairs<NB>(p, P0[k]);
+                    load_pairs<NB>(p + L.w, P1[k]);
                 }
+            } else {
 #pragma unroll
-                for (int c = 0; c < PPL; c++) { P0[c] = pack16(jb[0][c], jb[0][c + 1]); P1[c] = pack16(jb[1][c], jb[1][c + 1]); }
+                for (int k = 0; k < SPL; k++) {
+                    int jb[2][NB];
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const uint8_t* rp = Bm + (size_t)reflect101(iny + sg.row[k] + r, L.h) * L.w;
+#pragma unroll
+                        for (int c = 0; c < NB; c++) jb[r][c] = rp[reflect101(inx + sg.xs[k] + c, L.w)];
+                    }
+#pragma unroll
+                    for (int c = 0; c < PPL; c++) { P0[k][c] = pack16(jb[0][c], jb[0][c + 1]); P1[k][c] = pack16(jb[1][c], jb[1][c + 1]); }
+                }
             }
             const float fx0 = (float)inx, fy0 = (float)iny;
             for (;;) {
@@ -256,12 +268,14 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 w0 = pack16(iw00, iw01); w1 = pack16(iw10, iw11);
                 int pb1 = 0, pb2 = 0;
 #pragma unroll
-                for (int jj = 0; jj < PPL; jj++) {
-                    // masked pixels have Ix = Iy = 0, so whatever diff they see contributes an exact zero
-                    int diff = (dot2(P1[jj], w1, dot2(P0[jj], w0, 1 << (LK_WBITS - 6))) >> (LK_WBITS - 5)) - Ir[jj];
-                    pb1 += __mul24(diff, Ixr[jj]); pb2 += __mul24(diff, Iyr[jj]);
-                }
-                const float b1 = wave_sum_to_float(pb1) * FLT_SCALE, b2 = wave_sum_to_float(pb2) * FLT_SCALE;
+                for (int k = 0; k < SPL; k++)
+#pragma unroll
+                    for (int jj = 0; jj < PPL; jj++) {
+                        // masked pixels have Ix = Iy = 0, so whatever diff they see contributes an exact zero
+                        int diff = (dot2(P1[k][jj], w1, dot2(P0[k][jj], w0, 1 << (LK_WBITS - 6))) >> (LK_WBITS - 5)) - Ir[k][jj];
+                        pb1 += __mul24(diff, Ixr[k][jj]); pb2 += __mul24(diff, Iyr[k][jj]);
+                    }
+                const float b1 = group_sum_to_float<G>(pb1) * FLT_SCALE, b2 = group_sum_to_float<G>(pb2) * FLT_SCALE;
                 const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
                 nx += dx; ny += dy;
                 outx = nx + half; outy = ny + half;
@@ -285,6 +299,21 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
     }
 }
 
+// per-lane description of the window segments it owns
+template <int W, int G>
+__device__ __forceinline__ void lk_segments(LkSegs<LkLayout<W, G>::SPL>& sg) {
+    using LL = LkLayout<W, G>;
+    const int li = threadIdx.x % G;
+#pragma unroll
+    for (int k = 0; k < LL::SPL; k++) {
+        const int sidx = li * LL::SPL + k;
+        sg.on[k] = sidx < LL::NSEG;
+        const int sc = sg.on[k] ? sidx : 0;          // idle slots shadow segment 0 so their loads stay in bounds
+        sg.row[k] = sc / LL::LPR;
+        sg.xs[k] = (sc % LL::LPR) * LL::PPL;
+    }
+}
+
 __device__ __forceinline__ LkCrit make_crit(const svo_config& c) {
     LkCrit k;
     int mc = c.lk_max_count; mc = mc < 0 ? 0 : (mc > 100 ? 100 : mc);       // TermCriteria normalisation (lkpyramid.cpp)
@@ -294,8 +323,9 @@ __device__ __forceinline__ LkCrit make_crit(const svo_config& c) {
 }
 
 // ---- fused circular matching: L0 -> L1 -> R1 -> R0 -> L0 + masks (vo.cpp:203-230, 341-359) ----
-template <int W>
+template <int W, int G>
 __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d) {
+    constexpr int FPW = 64 / G;                                       // features per wave
     const int seq = blockIdx.y;
     SeqState& s = d.st[seq];
     if (!s.active) return;
@@ -309,15 +339,20 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d) {
     const LkCrit crit = make_crit(d.cfg);
     const float thr = (float)d.cfg.circular_matching_success_threshold;                // findClosePoints takes a float32 (vo.h:432)
     const float Wf = (float)d.geom.W, Hf = (float)d.geom.H;
-    for (int idx = blockIdx.x; idx < n; idx += gridDim.x) {
+    LkSegs<LkLayout<W, G>::SPL> sg;
+    lk_segments<W, G>(sg);
+    const int slot = threadIdx.x / G;
+    for (int base = blockIdx.x * FPW; base < n; base += gridDim.x * FPW) {
+        const int idx = base + slot;
+        if (idx >= n) continue;                                       // whole group idle (group-uniform)
         const size_t o = (size_t)seq * d.CAP + idx;
         const float2 p0 = d.feat_xy[s.feat_buf][o];                  // pointsLeftT0 = currentVOFeatures.points (vo.cpp:338)
         float2 p1, p2, p3, p4; int st0, st1, st2, st3;
-        lk_pass<W>(d.geom, L0, L1, p0.x, p0.y, p1.x, p1.y, st0, crit);   // vo.cpp:203
-        lk_pass<W>(d.geom, L1, R1, p1.x, p1.y, p2.x, p2.y, st1, crit);   // vo.cpp:206
-        lk_pass<W>(d.geom, R1, R0, p2.x, p2.y, p3.x, p3.y, st2, crit);   // vo.cpp:209
-        lk_pass<W>(d.geom, R0, L0, p3.x, p3.y, p4.x, p4.y, st3, crit);   // vo.cpp:213
-        if (threadIdx.x == 0) {
+        lk_pass<W, G>(d.geom, L0, L1, p0.x, p0.y, p1.x, p1.y, st0, crit, sg);   // vo.cpp:203
+        lk_pass<W, G>(d.geom, L1, R1, p1.x, p1.y, p2.x, p2.y, st1, crit, sg);   // vo.cpp:206
+        lk_pass<W, G>(d.geom, R1, R0, p2.x, p2.y, p3.x, p3.y, st2, crit, sg);   // vo.cpp:209
+        lk_pass<W, G>(d.geom, R0, L0, p3.x, p3.y, p4.x, p4.y, st3, crit, sg);   // vo.cpp:213
+        if (threadIdx.x % G == 0) {
             float ex = fabsf(p0.x - p4.x), ey = fabsf(p0.y - p4.y);
             float off = (ex < ey) ? ey : ex;
             int circ = st0 && st1 && st2 && st3 && !(off > thr);                        // vo.cpp:227-230
@@ -332,24 +367,32 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d) {
 }
 
 // ---- single pass, for the cv::calcOpticalFlowPyrLK-shaped stage API ----
-template <int W>
+template <int W, int G>
 __global__ __launch_bounds__(64) void k_lk_single(DevBuffers d, int slotA, int camA, int slotB, int camB, int n,
                                                   const float2* prev, float2* next, uint8_t* status) {
+    constexpr int FPW = 64 / G;
     const uint8_t* A = d.pyr + pyr_index(d, 0, slotA, camA);
     const uint8_t* Bp = d.pyr + pyr_index(d, 0, slotB, camB);
     const LkCrit crit = make_crit(d.cfg);
-    for (int idx = blockIdx.x; idx < n; idx += gridDim.x) {
+    LkSegs<LkLayout<W, G>::SPL> sg;
+    lk_segments<W, G>(sg);
+    const int slot = threadIdx.x / G;
+    for (int base = blockIdx.x * FPW; base < n; base += gridDim.x * FPW) {
+        const int idx = base + slot;
+        if (idx >= n) continue;
         float2 p = prev[idx], q; int st;
-        lk_pass<W>(d.geom, A, Bp, p.x, p.y, q.x, q.y, st, crit);
-        if (threadIdx.x == 0) { next[idx] = q; status[idx] = (uint8_t)st; }
+        lk_pass<W, G>(d.geom, A, Bp, p.x, p.y, q.x, q.y, st, crit, sg);
+        if (threadIdx.x % G == 0) { next[idx] = q; status[idx] = (uint8_t)st; }
     }
 }
 
-#define LK_MAX_GRID 4096
-#define LK_FOR_EACH_WINDOW(X) X(7) X(10) X(15) X(21) X(31)
+#define LK_MAX_GRID 16384
+// window -> lanes per feature, chosen by measurement on MI355X (32 sequences, LK chain ms): W=10: G=16 1.05 vs G=64 1.26;
+// W=15: 1.81 vs 1.55; W=21: 2.74 (G=16) / 2.33 (G=32) / 2.04 (G=64).  Small windows: one DPP row per feature, 4 per wave.
+#define LK_FOR_EACH_WINDOW(X) X(7, 16) X(10, 16) X(15, 64) X(21, 64) X(31, 64)
 
 bool lk_window_supported(int win) {
-#define CHK(Wn) if (win == Wn) return true;
+#define CHK(Wn, Gn) if (win == Wn) return true;
     LK_FOR_EACH_WINDOW(CHK)
 #undef CHK
     return false;
@@ -358,9 +401,8 @@ bool lk_window_supported(int win) {
 void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
     if (grid_n < 1) grid_n = 1;
     if (grid_n > d.CAP) grid_n = d.CAP;
-    if (grid_n > LK_MAX_GRID) grid_n = LK_MAX_GRID;               // the kernel strides over features
-    dim3 g(grid_n, d.B);
-#define LAUNCH(Wn) if (d.cfg.win_w == Wn) { hipLaunchKernelGGL(k_lk_chain<Wn>, g, dim3(64), 0, st, d); return; }
+#define LAUNCH(Wn, Gn) if (d.cfg.win_w == Wn) { int gx = (grid_n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
+        hipLaunchKernelGGL((k_lk_chain<Wn, Gn>), dim3(gx, d.B), dim3(64), 0, st, d); return; }
     LK_FOR_EACH_WINDOW(LAUNCH)
 #undef LAUNCH
 }
@@ -368,7 +410,8 @@ void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
 void launch_lk_single(const DevBuffers& d, int slotA, int camA, int slotB, int camB, int n, const float2* prev, float2* next,
                       uint8_t* status, hipStream_t st) {
     if (n <= 0) return;
-#define LAUNCH(Wn) if (d.cfg.win_w == Wn) { hipLaunchKernelGGL(k_lk_single<Wn>, dim3(n < LK_MAX_GRID ? n : LK_MAX_GRID), dim3(64), 0, st, d, slotA, camA, slotB, camB, n, prev, next, status); return; }
+#define LAUNCH(Wn, Gn) if (d.cfg.win_w == Wn) { int gx = (n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
+        hipLaunchKernelGGL((k_lk_single<Wn, Gn>), dim3(gx), dim3(64), 0, st, d, slotA, camA, slotB, camB, n, prev, next, status); return; }
     LK_FOR_EACH_WINDOW(LAUNCH)
 #undef LAUNCH
 }

@@ -154,6 +154,7 @@ static __device__ void svd_solve_ws(const double* A, const double* b, double* x,
 // Householder QR least squares for the 6 x 4 Gauss-Newton step; everything in the workspace (A 24, b 6, x 4, A1 4, A2 4)
 static __device__ bool qr_solve64(double* A, double* b, double* x, double* A1, double* A2) {
     const int M = 6, N = 4;
+#pragma unroll 1
     for (int k = 0; k < N; k++) {
         double eta = 0;
         for (int i = k; i < M; i++) { double e = fabs(A[i * N + k]); if (eta < e) eta = e; }
@@ -189,8 +190,10 @@ static __device__ bool qr_solve64(double* A, double* b, double* x, double* A1, d
 
 static __device__ void epnp_gauss_newton(const double* L, const double* rho, double* betas, double* ws) {
     double* A = ws; double* B = ws + 24; double* X = ws + 30; double* A1 = ws + 34; double* A2 = ws + 38;
+#pragma unroll 1
     for (int it = 0; it < 5; it++) {
         const double b0 = betas[0], b1 = betas[1], b2 = betas[2], b3 = betas[3];
+#pragma unroll 1
         for (int i = 0; i < 6; i++) {
             const double* rl = L + 10 * i; double* ra = A + 4 * i;
             ra[0] = 2 * rl[0] * b0 + rl[1] * b1 + rl[3] * b2 + rl[6] * b3;
@@ -294,6 +297,7 @@ static __device__ void epnp_setup(double* ar, double fu, double fv, double uc, d
         }
     }
     double* M = ar + EA_M; double* MtM = ar + EA_AT; double* Vt = ar + EA_VT; double* Wv = ar + EA_W;
+#pragma unroll 1
     for (int i = 0; i < n; i++) {
         double* M1 = M + 24 * i; double* M2 = M1 + 12; const double* as = alphas + 4 * i;
         double u = us[2 * i], v = us[2 * i + 1];
@@ -302,12 +306,16 @@ static __device__ void epnp_setup(double* ar, double fu, double fv, double uc, d
             M2[3 * j] = 0.0; M2[3 * j + 1] = as[j] * fv; M2[3 * j + 2] = as[j] * (vc - v);
         }
     }
-    for (int i = 0; i < 12; i++) for (int j = i; j < 12; j++) {
-        double s = 0;
-        for (int k = 0; k < 2 * n; k++) s += M[12 * k + i] * M[12 * k + j];
-        MtM[12 * i + j] = MtM[12 * j + i] = s;
-    }
+#pragma unroll 1
+    for (int i = 0; i < 12; i++)
+#pragma unroll 1
+        for (int j = i; j < 12; j++) {
+            double s = 0;
+            for (int k = 0; k < 2 * n; k++) s += M[12 * k + i] * M[12 * k + j];
+            MtM[12 * i + j] = MtM[12 * j + i] = s;
+        }
     // MtM is exactly symmetric, i.e. its own transpose: the one-sided Jacobi runs in place on it
+#pragma unroll 1
     for (int i = 0; i < 12; i++) {
         double sd = 0;
         for (int k = 0; k < 12; k++) { double tt = MtM[i * 12 + k]; sd += tt * tt; }
@@ -320,11 +328,13 @@ static __device__ void epnp_setup(double* ar, double fu, double fv, double uc, d
 // phase 3 (one lane): singular values, the descending selection sort applied to Vt, then L (6x10) and rho
 static __device__ void epnp_sort_and_L(double* ar) {
     double* At = ar + EA_AT; double* Vt = ar + EA_VT; double* Wv = ar + EA_W; double* cws = ar + EA_CWS;
+#pragma unroll 1
     for (int i = 0; i < 12; i++) {
         double sd = 0;
         for (int k = 0; k < 12; k++) { double tt = At[i * 12 + k]; sd += tt * tt; }
         Wv[i] = sqrt(sd);
     }
+#pragma unroll 1
     for (int i = 0; i < 11; i++) {
         int j = i;
         for (int k = i + 1; k < 12; k++) if (Wv[j] < Wv[k]) j = k;
@@ -344,6 +354,7 @@ static __device__ void epnp_sort_and_L(double* ar) {
             if (b > 3) { a++; b = a + 1; }
         }
     }
+#pragma unroll 1
     for (int i = 0; i < 6; i++) {
         double* row = L + 10 * i;
         const double* d0 = dv + (0 * 6 + i) * 3; const double* d1 = dv + (1 * 6 + i) * 3;

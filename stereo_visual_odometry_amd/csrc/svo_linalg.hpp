@@ -27,9 +27,12 @@ __device__ void jacobi_svd(PA At, PW Wv, PA Vt, int n1) {
         for (int k = 0; k < N; k++) Vt[i * N + k] = 0;
         Vt[i * N + i] = 1;
     }
+#pragma unroll 1
     for (int iter = 0; iter < max_iter; iter++) {
         bool changed = false;
+#pragma unroll 1
         for (int i = 0; i < N - 1; i++)
+#pragma unroll 1
             for (int j = i + 1; j < N; j++) {
                 PA Ai = At + i * M; PA Aj = At + j * M;
                 double a = Wv[i], p = 0, b = Wv[j], c, s;
