@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic sequences rendered per rank")
     ap.add_argument("--frames", type=int, default=10, help="frames rendered per pool sequence (ping-pong replay)")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -62,13 +64,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.same_device:
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")     # where collective payloads live
 
     # ---- workload: BASELINE.json configs[1] — KITTI-00 shaped 1241x376, ~2000 FAST features, LK 21x21, maxLevel 3
     cal = syn.KITTI00
@@ -138,22 +146,24 @@ def main():
     t0 = time.perf_counter()
     run(args.warmup + 1, args.steps, True)
     if world > 1:                                            # the path's only exchange: pose streams -> rank 0 (RCCL over xGMI)
-        gathered = sharding.gather_pose_streams(torch.from_numpy(poses).to(dev), dst=0)
+        gathered = sharding.gather_pose_streams(torch.from_numpy(poses).to(comm_dev), dst=0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        okt = torch.tensor([n_ok], dtype=torch.float64, device=dev)
+        okt = torch.tensor([n_ok], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(okt)
         n_ok_all = int(okt.item())
     else:
         n_ok_all = n_ok
 
     if rank == 0:
+        if world > 1:                                         # rank 0 now holds every sequence's pose stream
+            assert len(gathered) == world and all(tuple(g.shape) == (B, args.steps, 17) for g in gathered)
         N = float(np.mean(n_lk))
         bytes_total, bytes_lk = algorithmic_bytes(W, H, N, 21, 3, 100)
         lk_avg_ms = float(np.mean(lk_ms))

@@ -71,6 +71,7 @@ struct svo_context {
     int head = 0, tail = 0, inflight = 0;        // ring indices: head = next to enqueue, tail = oldest outstanding
     int last_slot = -1;
     uint8_t* staging = nullptr;                  // device [2][B][W*H] for host-image calls
+    uint8_t* h_staging = nullptr;                // pinned host mirror of `staging`
     bool projection_set = false;
     int lk_grid = 0;
 };
@@ -158,6 +159,7 @@ extern "C" void svo_destroy(svo_context* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (void* p : c->allocs) hipFree(p);
     if (c->staging) hipFree(c->staging);
+    if (c->h_staging) hipHostFree(c->h_staging);
     if (c->h_results) hipHostFree(c->h_results);
     if (c->h_ptrs) hipHostFree((void*)c->h_ptrs);
     for (int i = 0; i < SVO_RING; i++) {
@@ -263,14 +265,18 @@ extern "C" int svo_process_batch(svo_context* c, const uint8_t* const* left, con
         // the caller's buffers are only borrowed for the duration of the call: copy to the device first (SURVEY.md §8b "Ownership")
         const size_t img = (size_t)W * H;
         if (!c->staging) HIPCHK(hipMalloc((void**)&c->staging, img * 2 * B));
+        if (!c->h_staging) HIPCHK(hipHostMalloc((void**)&c->h_staging, img * 2 * B));
+        // rows are packed into pinned memory on the CPU (handles any stride), then ONE contiguous async H2D copy
+        // (a 2-D copy from pageable memory degenerates into per-row transfers: 3.5 ms per 1241x376 image)
         std::vector<const uint8_t*> lp(B), rp(B);
         for (int i = 0; i < B; i++) {
             if (!left[i] || !right[i]) return fail_arg("null image pointer");
-            uint8_t* dl = c->staging + img * i; uint8_t* dr = c->staging + img * (B + i);
-            HIPCHK(hipMemcpy2DAsync(dl, W, left[i], stride, W, H, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hipMemcpy2DAsync(dr, W, right[i], stride, W, H, hipMemcpyHostToDevice, c->stream));
-            lp[i] = dl; rp[i] = dr;
+            uint8_t* hl = c->h_staging + img * i; uint8_t* hr = c->h_staging + img * (B + i);
+            if (stride == W) { memcpy(hl, left[i], img); memcpy(hr, right[i], img); }
+            else for (int y = 0; y < H; y++) { memcpy(hl + (size_t)y * W, left[i] + (size_t)y * stride, W); memcpy(hr + (size_t)y * W, right[i] + (size_t)y * stride, W); }
+            lp[i] = c->staging + img * i; rp[i] = c->staging + img * (B + i);
         }
+        HIPCHK(hipMemcpyAsync(c->staging, c->h_staging, img * 2 * B, hipMemcpyHostToDevice, c->stream));
         rc = enqueue_frame(c, lp.data(), rp.data(), W);
     }
     if (rc != SVO_OK) return rc;
