@@ -31,6 +31,7 @@ struct SeqState {
     int n_circ;                               // tracks after circular mask only (vo.cpp:239)
     int fail_reason;
     int pnp_best, pnp_iters, pnp_good;
+    int pnp_need;                             // hypotheses that may still be consulted by the adaptive RANSAC loop
     int n_inliers;
     int ok;
     double R[9], t[3], last_T[16];            // vo.h:266-268

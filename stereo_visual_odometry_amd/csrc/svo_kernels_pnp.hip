@@ -17,6 +17,7 @@
 #include "svo_linalg.hpp"
 
 static __device__ __forceinline__ bool seq_live(const SeqState& s) { return s.active && s.fail_reason == 0; }
+static __device__ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
 
 // ------------------------------------------------------------------------------------------------ triangulation
 __global__ __launch_bounds__(64) void k_triangulate(DevBuffers d) {
@@ -405,14 +406,18 @@ static __device__ void epnp_branch(double* ar, int branch, double fu, double fv,
     res[0] = epnp_compute_R_and_t(ar, be, res + 1, res + 10, ws, fu, fv, uc, vc);
 }
 
-__global__ __launch_bounds__(EP_G * EP_HPB) void k_pnp_epnp(DevBuffers d) {
+// Hypotheses [h0, h1).  The first chunk (h0 == 0) is always solved; later chunks only up to s.pnp_need, the bound the
+// adaptive loop had reached after the first chunk (the bound only ever shrinks, so nothing beyond it can be consulted).
+__global__ __launch_bounds__(EP_G * EP_HPB) void k_pnp_epnp(DevBuffers d, int h0, int h1) {
     __shared__ double arena[EP_HPB * EP_STRIDE];
     const int seq = blockIdx.y;
     const SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
+    const int hend = h0 > 0 ? (s.pnp_need < h1 ? s.pnp_need : h1) : h1;
+    if (h0 + (int)blockIdx.x * EP_HPB >= hend) return;                  // block-uniform
     const int g = threadIdx.x / EP_G, q = threadIdx.x % EP_G;
-    const int h = blockIdx.x * EP_HPB + g;
-    const bool valid = h < d.K;
+    const int h = h0 + blockIdx.x * EP_HPB + g;
+    const bool valid = h < hend;
     double* ar = arena + g * EP_STRIDE;
     const double fx = s.K[0], fy = s.K[4], cx = s.K[2], cy = s.K[5];
     if (valid && q == 0) {
@@ -478,10 +483,11 @@ static __device__ __forceinline__ bool point_is_inlier(const double* Rt, double 
     return e <= thr2;
 }
 
-__global__ __launch_bounds__(256) void k_pnp_score(DevBuffers d) {
-    const int seq = blockIdx.y, h = blockIdx.x;
+__global__ __launch_bounds__(256) void k_pnp_score(DevBuffers d, int h0, int h1) {
+    const int seq = blockIdx.y, h = h0 + blockIdx.x;
     const SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
+    if (h >= (h0 > 0 ? (s.pnp_need < h1 ? s.pnp_need : h1) : h1)) return;
     __shared__ int total;
     __shared__ double Rt[12];
     if (threadIdx.x == 0) total = 0;
@@ -528,6 +534,26 @@ static __device__ void chol_solve6(const double* A, const double* b, double* x) 
     double y[6];
     for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= Lm[6 * i + k] * y[k]; y[i] = s / Lm[6 * i + i]; }
     for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= Lm[6 * k + i] * x[k]; x[i] = s / Lm[6 * i + i]; }
+}
+
+// After the first chunk: run the accept / shrink rule over its counts and publish how many iterations the serial loop
+// could still reach (RANSACPointSetRegistrator::run: niters only decreases).
+__global__ void k_pnp_decide(DevBuffers d, int c0) {
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= d.B) return;
+    SeqState& s = d.st[seq];
+    if (!seq_live(s)) return;
+    const int K = d.K, n = s.n_tracks;
+    const int* good = d.hyp_good + (size_t)seq * K;
+    int niters = K > 1 ? K : 1, max_good = 0;
+    for (int it = 0; it < niters && it < c0 && it < K; it++) {
+        int g = good[it];
+        if (g > (max_good > 4 ? max_good : 4)) {
+            max_good = g;
+            niters = ransac_update_num_iters((double)d.cfg.ransac_confidence, (double)(n - g) / n, 5, niters);
+        }
+    }
+    s.pnp_need = niters < K ? niters : K;
 }
 
 #define PF_THREADS 256
@@ -719,9 +745,16 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
     }
 }
 
+#define PNP_FIRST_CHUNK 16
 void launch_pnp(const DevBuffers& d, hipStream_t st) {
     hipLaunchKernelGGL(k_pnp_subsets, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
-    hipLaunchKernelGGL(k_pnp_epnp, dim3((d.K + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d);
-    hipLaunchKernelGGL(k_pnp_score, dim3(d.K, d.B), dim3(256), 0, st, d);
+    const int c0 = d.K < PNP_FIRST_CHUNK ? d.K : PNP_FIRST_CHUNK;
+    hipLaunchKernelGGL(k_pnp_epnp, dim3((c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, 0, c0);
+    hipLaunchKernelGGL(k_pnp_score, dim3(c0, d.B), dim3(256), 0, st, d, 0, c0);
+    if (d.K > c0) {
+        hipLaunchKernelGGL(k_pnp_decide, dim3((d.B + 63) / 64), dim3(64), 0, st, d, c0);
+        hipLaunchKernelGGL(k_pnp_epnp, dim3((d.K - c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, c0, d.K);
+        hipLaunchKernelGGL(k_pnp_score, dim3(d.K - c0, d.B), dim3(256), 0, st, d, c0, d.K);
+    }
     hipLaunchKernelGGL(k_pnp_final, dim3(d.B), dim3(PF_THREADS), 0, st, d);
 }
