@@ -169,11 +169,15 @@ def main():
         lk_avg_ms = float(np.mean(lk_ms))
         achieved = bytes_lk * Bc / (lk_avg_ms * 1e-3) / 1e9    # algorithmic GB/s of the dominant kernel: one launch covers Bc sequences
         value = world * B * args.steps / dt
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+        # separate runs of this same script, profiles/summarize.py), rescaled to this run's sequences per launch
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_lk_chain_pmc.json")
-        if os.path.exists(pmc):
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_lk_chain_pmc.json")))
+        if pmcs:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                j = json.load(open(pmcs[-1]))
+                traffic = j["hbm_bytes_per_launch"] * Bc / float(j.get("sequences_per_launch", 32))
             except Exception:
                 traffic = None
         cpu = None

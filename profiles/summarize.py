@@ -30,19 +30,21 @@ def pmc_mean(d, counter, kernel, drop_small=True):
 
 
 def main():
-    a = [x for x in sys.argv[1:] if not x.startswith("--")]
+    a = [x for i, x in enumerate(sys.argv[1:], 1) if not x.startswith("--") and sys.argv[i - 1] not in ("--seqs", "--kernel")]
     kernel = "k_lk_chain"
     if "--kernel" in sys.argv:
         kernel = sys.argv[sys.argv.index("--kernel") + 1]
-        a = [x for x in a if x != kernel]
     tag, stats = a[0], a[1]
     here = os.path.dirname(os.path.abspath(__file__))
     shutil.copy(find(stats, "*kernel_stats.csv"), os.path.join(here, tag + "_kernel_stats.csv"))
     if len(a) >= 4:
         f, nf = pmc_mean(a[2], "FETCH_SIZE", kernel)
         w, nw = pmc_mean(a[3], "WRITE_SIZE", kernel)
+        seqs = 32
+        if "--seqs" in sys.argv:
+            seqs = int(sys.argv[sys.argv.index("--seqs") + 1])
         out = {"kernel": kernel, "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "launches": [nf, nw],
-               "hbm_bytes_per_launch": (f + w) * 1024,
+               "sequences_per_launch": seqs, "hbm_bytes_per_launch": (f + w) * 1024,
                "note": "separate --pmc passes; units KB*1024; FETCH_SIZE uncorrected (byte-gather access, uncalibrated per MI355X_MICROARCH.md §HBM)"}
         json.dump(out, open(os.path.join(here, tag + "_lk_chain_pmc.json"), "w"), indent=1)
         print(out)
