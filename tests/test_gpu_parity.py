@@ -386,3 +386,31 @@ def test_outlier_scene_exercises_adaptive_ransac(api):
             im_a[60:200, 380:640] = im_b[60:200, 380:640]
     res = run_both(api, a, dict(win_w=21, win_h=21, max_translation_norm=2.0, ransac_reprojection_error=1.0), 3)
     assert any(r[2]["ransac_iters"] > 1 for r in res[1:])
+
+
+def test_long_sequence_parity_crosses_age_threshold(api):
+    """26 frames of slow motion: tracks survive long enough to reach AGE_THRESHOLD = 20 and get dropped at bucketing
+    (feature_set.cpp:26, SURVEY B-8); every frame must stay bit-exact against the oracle."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=400, height=180, cx=200.0, cy=90.0)
+    seq = syn.StereoSequence(cal=cal, n_frames=26, seed=77, step=0.05, yaw_amp_deg=0.05)
+    Pl, Pr = syn.projection_matrices(cal)
+    ovo = orc.VisualOdometry(orc.default_config(win_w=21, win_h=21)); ovo.initalize_projection_matricies(Pl, Pr)
+    gvo = api.VisualOdometry(cfg=api.default_config(win_w=21, win_h=21)); gvo.initalize_projection_matricies(Pl, Pr)
+    max_age, dropped_old = 0, False
+    prev_ages = None
+    for k in range(26):
+        ok_o, T_o = ovo.stereo_callback(seq.left[k], seq.right[k])
+        ok_g, T_g = gvo.stereo_callback(seq.left[k], seq.right[k])
+        assert ok_o == ok_g, k
+        assert {f[0]: getattr(ovo.stats, f[0]) for f in ovo.stats._fields_} == gvo.stats.as_dict(), k
+        fo, fg = ovo.features(), gvo.features()
+        assert np.array_equal(bits(fo[0]), bits(fg[0])) and np.array_equal(fo[1], fg[1]) and np.array_equal(fo[2], fg[2]), k
+        assert np.abs(T_o - T_g).max() < 1e-6, k
+        if len(fg[1]):
+            max_age = max(max_age, int(fg[1].max()))
+        if prev_ages is not None and (prev_ages >= 19).any():
+            dropped_old = True
+        prev_ages = fg[1].copy()
+    assert max_age >= 20 and dropped_old          # the age gate was really exercised
+    assert int(fg[1].max()) <= 20                  # nothing older than the threshold survives a bucketing
