@@ -78,6 +78,41 @@ __device__ __forceinline__ float group_sum_to_float(int partial) {
     return (float)shi * 65536.f + (float)slo;
 }
 
+// N independent exact sums at once, the DPP steps of the 2N half-sums issued round-robin so every DPP instruction has
+// independent work between it and its predecessor (DPP needs 2 wait states after a VALU write of its source).
+template <int G, int N>
+__device__ __forceinline__ void group_sums_to_float(const int (&partial)[N], float (&out)[N]) {
+    int v[2 * N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { v[2 * i] = partial[i] & 0xFFFF; v[2 * i + 1] = partial[i] >> 16; }
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0xB1, 0xF, 0xF, true);
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x4E, 0xF, 0xF, true);
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x141, 0xF, 0xF, true);
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x140, 0xF, 0xF, true);
+    if (G == 64) {
+#pragma unroll
+        for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x142, 0xA, 0xF, false);
+#pragma unroll
+        for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x143, 0xC, 0xF, false);
+#pragma unroll
+        for (int i = 0; i < 2 * N; i++) v[i] = __builtin_amdgcn_readlane(v[i], 63);
+    }
+    if (G == 32) {
+#pragma unroll
+        for (int i = 0; i < 2 * N; i++) {
+            const int r0 = __builtin_amdgcn_readlane(v[i], 0) + __builtin_amdgcn_readlane(v[i], 16);
+            const int r1 = __builtin_amdgcn_readlane(v[i], 32) + __builtin_amdgcn_readlane(v[i], 48);
+            v[i] = (threadIdx.x & 32) ? r1 : r0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) out[i] = (float)v[2 * i + 1] * 65536.f + (float)v[2 * i];
+}
+
 __device__ __forceinline__ void lk_weights(float a, float b, int& iw00, int& iw01, int& iw10, int& iw11) {
     iw00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << LK_WBITS));
     iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << LK_WBITS));
@@ -220,7 +255,9 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 pA11 += __mul24(Ixr[k][j], Ixr[k][j]); pA12 += __mul24(Ixr[k][j], Iyr[k][j]); pA22 += __mul24(Iyr[k][j], Iyr[k][j]);
             }
         }
-        const float A11 = group_sum_to_float<G>(pA11) * FLT_SCALE, A12 = group_sum_to_float<G>(pA12) * FLT_SCALE, A22 = group_sum_to_float<G>(pA22) * FLT_SCALE;
+        float As[3];
+        { const int pa[3] = {pA11, pA12, pA22}; group_sums_to_float<G, 3>(pa, As); }
+        const float A11 = As[0] * FLT_SCALE, A12 = As[1] * FLT_SCALE, A22 = As[2] * FLT_SCALE;
         float Dt = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * W * W);
         if ((double)minEig < crit.min_eig || Dt < 1.1920928955078125e-07f) {
@@ -275,7 +312,9 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                         int diff = (dot2(P1[k][jj], w1, dot2(P0[k][jj], w0, 1 << (LK_WBITS - 6))) >> (LK_WBITS - 5)) - Ir[k][jj];
                         pb1 += __mul24(diff, Ixr[k][jj]); pb2 += __mul24(diff, Iyr[k][jj]);
                     }
-                const float b1 = group_sum_to_float<G>(pb1) * FLT_SCALE, b2 = group_sum_to_float<G>(pb2) * FLT_SCALE;
+                float bs[2];
+                { const int pb[2] = {pb1, pb2}; group_sums_to_float<G, 2>(pb, bs); }
+                const float b1 = bs[0] * FLT_SCALE, b2 = bs[1] * FLT_SCALE;
                 const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
                 nx += dx; ny += dy;
                 outx = nx + half; outy = ny + half;
