@@ -557,6 +557,22 @@ __global__ void k_pnp_decide(DevBuffers d, int c0) {
 }
 
 #define PF_THREADS 256
+// the value of lane (dpp-permuted) of a double: DPP works on 32-bit registers, so move the halves separately
+static __device__ __forceinline__ double dpp_f64(double v, const int ctrl_unused);
+template <int CTRL> static __device__ __forceinline__ double dpp_f64_t(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ double dpp_f64(double v, const int ctrl) {
+    switch (ctrl) {
+        case 0xB1: return dpp_f64_t<0xB1>(v);
+        case 0x4E: return dpp_f64_t<0x4E>(v);
+        case 0x141: return dpp_f64_t<0x141>(v);
+        default: return dpp_f64_t<0x140>(v);
+    }
+}
 struct LmShared {
     double param[6], prev[6], R[9], dRdr[27], JtJ[36], JtErr[6];
     double red[4][28];
@@ -601,14 +617,20 @@ static __device__ void lm_eval(const DevBuffers& d, const SeqState& s, size_t o,
             for (int a = 0; a < 6; a++) acc[21 + a] += jx[a] * ex + jy[a] * ey;
         }
     }
+    // block reduction: wave level with DPP row steps on the two 32-bit halves of each double (no LDS shuffles), then LDS
+    // across the 4 waves.  A residual-only evaluation needs just the error norm (slot 27).
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int k = 0; k < 28; k++) {
+    const int k0 = with_J ? 0 : 27;
+    for (int k = k0; k < 28; k++) {
         double v = acc[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) sh.red[wv][k] = v;
+        v += dpp_f64(v, 0xB1); v += dpp_f64(v, 0x4E); v += dpp_f64(v, 0x141); v += dpp_f64(v, 0x140);   // sum of the 16-lane row in every lane
+        // rows -> wave: lanes 0, 16, 32, 48 hold the row sums
+        double r = v + __shfl(v, (lane + 16) & 63) ;
+        r = r + __shfl(r, (lane + 32) & 63);
+        if (lane == 0) sh.red[wv][k] = r;
     }
     __syncthreads();
-    if (threadIdx.x < 28) sh.red[0][threadIdx.x] = sh.red[0][threadIdx.x] + sh.red[1][threadIdx.x] + sh.red[2][threadIdx.x] + sh.red[3][threadIdx.x];
+    if (threadIdx.x >= k0 && threadIdx.x < 28) sh.red[0][threadIdx.x] = sh.red[0][threadIdx.x] + sh.red[1][threadIdx.x] + sh.red[2][threadIdx.x] + sh.red[3][threadIdx.x];
     __syncthreads();
 }
 
