@@ -17,6 +17,16 @@ if not os.path.exists(LIB_PATH):
         "(python -c 'import __graft_entry__ as g; g.build()' or make -C stereo_visual_odometry_amd/csrc). "
         "There is no CPU fallback." % LIB_PATH)
 
+# Load order: the PyTorch ROCm wheel bundles its own libamdhip64 / libhsa-runtime64.  If the system ROCm runtime (a
+# dependency of libsvo_hip.so) is initialised first, torch's copy later reports "No HIP GPUs are available"; the other order
+# works (measured on the MI355X box).  torch is plumbing here (device tensors in bench.py), so when it is installed it is
+# imported first.  Set SVO_NO_TORCH_PRELOAD=1 to skip.
+if not os.environ.get("SVO_NO_TORCH_PRELOAD"):
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
 lib = C.CDLL(LIB_PATH)
 
 SVO_OK, SVO_ERR_ARG, SVO_ERR_HIP, SVO_ERR_CAPACITY, SVO_ERR_STATE = 0, -1, -2, -3, -4
