@@ -386,11 +386,18 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d) {
         if (idx >= n) continue;                                       // whole group idle (group-uniform)
         const size_t o = (size_t)seq * d.CAP + idx;
         const float2 p0 = d.feat_xy[s.feat_buf][o];                  // pointsLeftT0 = currentVOFeatures.points (vo.cpp:338)
-        float2 p1, p2, p3, p4; int st0, st1, st2, st3;
-        lk_pass<W, G>(d.geom, L0, L1, p0.x, p0.y, p1.x, p1.y, st0, crit, sg);   // vo.cpp:203
-        lk_pass<W, G>(d.geom, L1, R1, p1.x, p1.y, p2.x, p2.y, st1, crit, sg);   // vo.cpp:206
-        lk_pass<W, G>(d.geom, R1, R0, p2.x, p2.y, p3.x, p3.y, st2, crit, sg);   // vo.cpp:209
-        lk_pass<W, G>(d.geom, R0, L0, p3.x, p3.y, p4.x, p4.y, st3, crit, sg);   // vo.cpp:213
+        // the four passes share ONE inlined copy of lk_pass (a loop, not four copies): 4x less code in the instruction cache
+        float2 p1 = p0, p2 = p0, p3 = p0, p4 = p0; int st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+        float2 cur = p0;
+#pragma unroll 1
+        for (int pass = 0; pass < 4; pass++) {
+            const uint8_t* A = pass == 0 ? L0 : pass == 1 ? L1 : pass == 2 ? R1 : R0;      // vo.cpp:203, 206, 209, 213
+            const uint8_t* Bq = pass == 0 ? L1 : pass == 1 ? R1 : pass == 2 ? R0 : L0;
+            float2 q; int st;
+            lk_pass<W, G>(d.geom, A, Bq, cur.x, cur.y, q.x, q.y, st, crit, sg);
+            if (pass == 0) { p1 = q; st0 = st; } else if (pass == 1) { p2 = q; st1 = st; } else if (pass == 2) { p3 = q; st2 = st; } else { p4 = q; st3 = st; }
+            cur = q;
+        }
         if (threadIdx.x % G == 0) {
             float ex = fabsf(p0.x - p4.x), ey = fabsf(p0.y - p4.y);
             float off = (ex < ey) ? ey : ex;
