@@ -36,3 +36,43 @@ def gather_pose_streams(local, dst=0):
     out = [local.new_empty(local.shape) for _ in range(world)] if rank == dst else None
     dist.gather(local, out, dst=dst)
     return out
+
+
+def gather_ragged_pose_streams(streams, dst=0, device=None):
+    """Sequences of different lengths (BASELINE configs[3]: KITTI 00-07 have 271 .. 4661 frames).
+    streams: list of (frames_i, 17) float64 numpy arrays owned by this rank (may be empty).
+    Every rank pads its streams to the global maximum length, one gather moves the padded block plus the true
+    lengths to rank dst, which strips the padding.  Returns on dst {sequence_id: (frames, 17) array} using the
+    s = rank + k * world_size ownership of shard_sequences; None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    dev = device if device is not None else torch.device("cpu")
+    n_local = torch.tensor([len(streams)], dtype=torch.int64, device=dev)
+    max_len = torch.tensor([max([len(x) for x in streams], default=0)], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(n_local, op=dist.ReduceOp.MAX)           # ranks may own different numbers of sequences
+        dist.all_reduce(max_len, op=dist.ReduceOp.MAX)
+    S, F = int(n_local.item()), int(max_len.item())
+    block = np.zeros((S, F, 17)); lens = np.full(S, -1, np.int64)
+    for k, x in enumerate(streams):
+        block[k, :len(x)] = x
+        lens[k] = len(x)
+    tb = torch.from_numpy(block).to(dev); tl = torch.from_numpy(lens).to(dev)
+    if world > 1:
+        ob = [torch.empty_like(tb) for _ in range(world)] if rank == dst else None
+        ol = [torch.empty_like(tl) for _ in range(world)] if rank == dst else None
+        dist.gather(tb, ob, dst=dst)
+        dist.gather(tl, ol, dst=dst)
+    else:
+        ob, ol = [tb], [tl]
+    if rank != dst:
+        return None
+    out = {}
+    for r in range(world):
+        b, l = ob[r].cpu().numpy(), ol[r].cpu().numpy()
+        for k in range(S):
+            if l[k] >= 0:
+                out[r + k * world] = b[k, :l[k]].copy()
+    return out

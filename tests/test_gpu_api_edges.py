@@ -136,3 +136,17 @@ def test_timing_and_stream_accessors(api):
     lk, fr = vo.last_timing()
     assert 0 < lk < fr < 1000
     assert vo.stream()
+
+
+def test_run_sequences_tool_ragged_lengths(tmp_path):
+    """BASELINE configs[3] in miniature: sequences of different lengths batched on one GPU, one CSV per sequence whose
+    end point matches the renderer's ground truth."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "run_sequences.py"), "--lengths", "6,3,5", "--width", "480", "--height", "200",
+                          "--out", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for s, n in enumerate((6, 3, 5)):
+        rows = np.loadtxt(tmp_path / ("result_seq%02d.csv" % s), delimiter=",", skiprows=1)
+        assert rows.shape == (n, 4) and rows[0, 3] == 0 and rows[1:, 3].all()
+        assert abs(rows[-1, 2] - 0.5 * (n - 1)) < 0.05          # 0.5 m per frame along +z

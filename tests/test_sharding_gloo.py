@@ -62,3 +62,41 @@ def test_gather_pose_streams_world2_gloo():
     for r in range(2):
         want = np.stack([_pose_stream_for(s, 6) for s in sharding.shard_sequences(4, r, 2)])
         assert np.array_equal(got[r], want)                       # every sequence's stream arrives intact, in rank order
+
+
+def _ragged_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lengths = [27, 11, 46, 8, 3]                                  # 5 sequences of different lengths over 2 ranks (3 + 2)
+    mine = [_pose_stream_for(s, lengths[s]) for s in sharding.shard_sequences(5, rank, world)]
+    out = sharding.gather_ragged_pose_streams(mine, dst=0)
+    if rank == 0:
+        q.put({k: v for k, v in out.items()})
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_ragged_pose_streams_world2_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    lengths = [27, 11, 46, 8, 3]
+    assert sorted(got) == [0, 1, 2, 3, 4]
+    for sid in range(5):
+        assert got[sid].shape == (lengths[sid], 17)
+        assert np.array_equal(got[sid], _pose_stream_for(sid, lengths[sid]))
+
+
+def test_gather_ragged_single_process():
+    out = sharding.gather_ragged_pose_streams([_pose_stream_for(0, 4), _pose_stream_for(1, 9)])
+    assert out[0].shape == (4, 17) and out[1].shape == (9, 17)
