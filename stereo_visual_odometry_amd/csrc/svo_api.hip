@@ -74,6 +74,7 @@ struct svo_context {
     uint8_t* h_staging = nullptr;                // pinned host mirror of `staging`
     bool projection_set = false;
     int lk_grid = 0;
+    int lk_hint = 0;                             // feature count seen in the last collected frame (sizes the LK grid; 0 = unknown)
 };
 
 template <typename T>
@@ -208,7 +209,12 @@ static int enqueue_frame(svo_context* c, const uint8_t* const* left_dev, const u
     launch_detect(d, 0, -1, s);
     launch_detect(d, 1, -1, s);
     HIPCHK(hipEventRecord(c->ev_lk0[slot], s));
-    launch_lk_chain(d, c->lk_grid, s);
+    // grid sized from the last feature counts the host has seen (+30 %); the kernel strides, so an underestimate is only slower
+    {
+        int gn = c->lk_grid;
+        if (c->lk_hint > 0) { int h = c->lk_hint + c->lk_hint / 3 + 64; if (h < gn) gn = h; }
+        launch_lk_chain(d, gn, s);
+    }
     HIPCHK(hipEventRecord(c->ev_lk1[slot], s));
     launch_compact(d, s);
     launch_triangulate(d, s);
@@ -230,6 +236,11 @@ static int collect_frame(svo_context* c, double* T_out, int* ok_out, svo_frame_s
         if (T_out) memcpy(T_out + 16 * i, r[i].T, sizeof(double) * 16);
         if (ok_out) ok_out[i] = r[i].ok;
         if (stats) stats[i] = r[i].stats;
+    }
+    {
+        int mx = 0;
+        for (int i = 0; i < B; i++) if (r[i].stats.n_after_detect > mx) mx = r[i].stats.n_after_detect;
+        if (mx > 0) c->lk_hint = mx;
     }
     c->last_slot = slot;
     c->tail = (c->tail + 1) % SVO_RING; c->inflight--;

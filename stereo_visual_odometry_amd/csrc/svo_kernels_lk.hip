@@ -23,6 +23,7 @@
 //     result is order-independent and bit-identical to the sequential CPU loop, and the float tail
 //     and every branch are wave-uniform.
 #include "svo_internal.hpp"
+#include <stdlib.h>
 
 #define LK_WBITS 14
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
@@ -362,15 +363,35 @@ __device__ __forceinline__ LkCrit make_crit(const svo_config& c) {
 }
 
 // ---- fused circular matching: L0 -> L1 -> R1 -> R0 -> L0 + masks (vo.cpp:203-230, 341-359) ----
+// Block -> (sequence, feature) mapping, two forms (launch argument `slots` > 0 / < 0):
+//  * plain (default): sequence-major, one block per feature, every sequence spread over all XCDs.
+//  * XCD-affine (SVO_LK_XCD=1): workgroups are dealt round-robin over the 8 XCDs (block b lands on XCD b % 8,
+//    MI355X_MICROARCH.md; used for speed only), each XCD has a private 4 MiB L2 and one sequence's four pyramids are
+//    2.5 MB, so XCD x is given the sequences x, x+8, ... and walks through them one at a time.
+// Measured on MI355X, 32 sequences per launch (rocprofv3 FETCH_SIZE, HIP-event time): plain 334 MB / 2.10 ms;
+// XCD-affine 39 MB / 2.26 ms (dispatch is in global block order and stalls on the busiest XCD); a persistent variant
+// pulling from per-XCD work queues (HW_REG_XCC_ID + atomicAdd, with stealing) 45 MB / 2.44 ms.  The kernel is
+// VALU-issue-bound and the extra fetches of the plain form are served by the Infinity Cache, so the fastest form is
+// the default and the affine one stays selectable for HBM-constrained deployments.
 template <int W, int G>
-__global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d) {
+__global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots) {
     constexpr int FPW = 64 / G;                                       // features per wave
-    const int seq = blockIdx.y;
+    int seq, fb;
+    if (slots > 0) {
+        const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+        const int jr = t / slots;                                     // round of sequences on this XCD
+        fb = t - jr * slots;                                          // feature block
+        seq = jr * 8 + xcd;
+    } else {                                                          // plain mapping: sequence-major
+        slots = -slots;
+        seq = blockIdx.x / slots; fb = blockIdx.x - seq * slots;
+    }
+    if (seq >= d.B) return;
     SeqState& s = d.st[seq];
     if (!s.active) return;
     int n = s.n_feat;
     if (d.cfg.max_features > 0 && n > d.cfg.max_features) n = d.cfg.max_features;
-    if (blockIdx.x == 0 && threadIdx.x == 0) s.n_lk = n;
+    if (fb == 0 && threadIdx.x == 0) s.n_lk = n;
     const uint8_t* L0 = d.pyr + pyr_index(d, seq, s.slot_pyr_t0, 0);
     const uint8_t* R0 = d.pyr + pyr_index(d, seq, s.slot_pyr_t0, 1);
     const uint8_t* L1 = d.pyr + pyr_index(d, seq, s.slot_t1, 0);
@@ -381,7 +402,7 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d) {
     LkSegs<LkLayout<W, G>::SPL> sg;
     lk_segments<W, G>(sg);
     const int slot = threadIdx.x / G;
-    for (int base = blockIdx.x * FPW; base < n; base += gridDim.x * FPW) {
+    for (int base = fb * FPW; base < n; base += slots * FPW) {
         const int idx = base + slot;
         if (idx >= n) continue;                                       // whole group idle (group-uniform)
         const size_t o = (size_t)seq * d.CAP + idx;
@@ -433,6 +454,7 @@ __global__ __launch_bounds__(64) void k_lk_single(DevBuffers d, int slotA, int c
 }
 
 #define LK_MAX_GRID 16384
+static int lk_xcd_mapping() { static int v = -1; if (v < 0) { const char* e = getenv("SVO_LK_XCD"); v = e ? atoi(e) : 0; } return v; }
 // window -> lanes per feature, chosen by measurement on MI355X (32 sequences, LK chain ms): W=10: G=16 1.05 vs G=64 1.26;
 // W=15: 1.81 vs 1.55; W=21: 2.74 (G=16) / 2.33 (G=32) / 2.04 (G=64).  Small windows: one DPP row per feature, 4 per wave.
 #define LK_FOR_EACH_WINDOW(X) X(7, 16) X(10, 16) X(15, 64) X(21, 64) X(31, 64)
@@ -448,7 +470,10 @@ void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
     if (grid_n < 1) grid_n = 1;
     if (grid_n > d.CAP) grid_n = d.CAP;
 #define LAUNCH(Wn, Gn) if (d.cfg.win_w == Wn) { int gx = (grid_n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
-        hipLaunchKernelGGL((k_lk_chain<Wn, Gn>), dim3(gx, d.B), dim3(64), 0, st, d); return; }
+        const int rounds = (d.B + 7) / 8; \
+        if (lk_xcd_mapping() == 1) hipLaunchKernelGGL((k_lk_chain<Wn, Gn>), dim3((unsigned)gx * 8u * (unsigned)rounds), dim3(64), 0, st, d, gx); \
+        else hipLaunchKernelGGL((k_lk_chain<Wn, Gn>), dim3((unsigned)gx * (unsigned)d.B), dim3(64), 0, st, d, -gx); \
+        return; }
     LK_FOR_EACH_WINDOW(LAUNCH)
 #undef LAUNCH
 }
