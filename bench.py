@@ -19,6 +19,24 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
 
 
+def host_cores():
+    """CPU cores this process may really use: the cgroup CPU quota if one is set (a GPU box exposes all of the host's
+    logical CPUs but grants a share of them), else the affinity mask; capped at 64."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]             # cgroup v2
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
 def level_sizes(W, H, win, max_level):
     out = []
     w, h = W, H
@@ -184,16 +202,24 @@ def main():
         if world == 1 and args.cpu_frames > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as orc
-            o = orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl, Pr)
-            s = pool[0]
-            o.stereo_callback(s.left[0], s.right[0])
-            c0 = time.perf_counter()
-            for i in range(1, args.cpu_frames + 1):
-                f = ping_pong(i)
-                o.stereo_callback(s.left[f], s.right[f])
-            cdt = time.perf_counter() - c0
-            cpu = {"value": args.cpu_frames / cdt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-                   "sample": "%d frame pairs of the same 1241x376 synthetic sequence through oracle/ (plain C, -O2, 1 thread)" % args.cpu_frames}
+
+            def cpu_rate(threads, frames):
+                used = orc.set_threads(threads)
+                o = orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl, Pr)
+                sq = pool[0]
+                o.stereo_callback(sq.left[0], sq.right[0])
+                c0 = time.perf_counter()
+                for i in range(1, frames + 1):
+                    f = ping_pong(i)
+                    o.stereo_callback(sq.left[f], sq.right[f])
+                return frames / (time.perf_counter() - c0), used
+
+            single, _ = cpu_rate(1, max(4, args.cpu_frames // 3))
+            allc, cores = cpu_rate(host_cores(), args.cpu_frames)   # every core this process is granted (OpenMP over LK points / image rows)
+            orc.set_threads(1)
+            cpu = {"value": allc, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                   "sample": "%d frame pairs of the same 1241x376 synthetic sequence through oracle/ (plain C -O2, OpenMP over the points "
+                             "of each LK pass and over image rows, %d threads); single thread: %.2f frame-pairs/s" % (args.cpu_frames, cores, single)}
         out = {
             "metric": "stereo frame-pairs/sec on KITTI-00 1241x376 @2k feats", "value": value, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

@@ -78,6 +78,9 @@ typedef struct {
 } orc_config;
 
 void orc_config_default(orc_config* c);
+/* threads used by the data-parallel loops (points inside each LK pass, image rows) — OpenCV's parallel_for_ analogue.
+   n <= 0 selects all cores; returns the count in effect.  Results do not depend on it. */
+int orc_set_threads(int n);
 
 /* ---- FAST-9/16 (cv::FAST, called at feature_set.cpp:61) ---- */
 /* Writes NMS-surviving corner scores (0 elsewhere) into score[h*w]. nonmax=0 writes raw corner flags as score. */

@@ -58,6 +58,7 @@ static void fast_raw_scores(const uint8_t* img, int w, int h, int stride, int th
     for (k = 0; k < 16; k++) off[k] = CIRC[k][0] + CIRC[k][1] * stride;
     for (k = 16; k < 25; k++) off[k] = off[k - 16];
     memset(raw, 0, (size_t)w * h);
+#pragma omp parallel for private(x)
     for (y = 3; y < h - 3; y++)
         for (x = 3; x < w - 3; x++) {
             const uint8_t* p = img + (size_t)y * stride + x;

@@ -16,8 +16,12 @@ static inline int reflect101(int i, int n) {
 
 /* pyrDown, 8-bit: separable [1 4 6 4 1], (sum + 128) >> 8, source border REFLECT_101. */
 void orc_pyr_down(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dstride) {
-    int dw = (sw + 1) / 2, dh = (sh + 1) / 2, x, y, k;
+    int dw = (sw + 1) / 2, dh = (sh + 1) / 2, y;
+#pragma omp parallel
+    {
+    int x, k;
     int* rows = (int*)malloc(sizeof(int) * (size_t)dw * 5);
+#pragma omp for
     for (y = 0; y < dh; y++) {
         for (k = 0; k < 5; k++) {
             int sy = reflect101(2 * y + k - 2, sh);
@@ -35,13 +39,18 @@ void orc_pyr_down(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst,
         }
     }
     free(rows);
+    }
 }
 
 /* calcSharrDeriv: int16 interleaved (dx,dy); REFLECT_101 at the image edges. */
 void orc_scharr(const uint8_t* src, int w, int h, int sstride, int16_t* dst, int dstride) {
-    int x, y;
+    int y;
+#pragma omp parallel
+    {
+    int x;
     int* t0 = (int*)malloc(sizeof(int) * (size_t)(w + 2));
     int* t1 = (int*)malloc(sizeof(int) * (size_t)(w + 2));
+#pragma omp for
     for (y = 0; y < h; y++) {
         const uint8_t* r0 = src + (size_t)reflect101(y - 1, h) * sstride;
         const uint8_t* r1 = src + (size_t)y * sstride;
@@ -60,6 +69,7 @@ void orc_scharr(const uint8_t* src, int w, int h, int sstride, int16_t* dst, int
         }
     }
     free(t0); free(t1);
+    }
 }
 
 static void make_level(orc_pyramid* p, int lvl, int w, int h) {
@@ -131,11 +141,16 @@ static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int 
     const uint8_t* J = B->img[level]; const int stepJ = B->img_stride[level];
     const int colsI = A->w[level], rowsI = A->h[level], colsJ = B->w[level], rowsJ = B->h[level];
     const float FLT_SCALE = 1.f / (1 << 20);
+    const float scale = (float)(1. / (1 << level));
+    int i;
+
+    /* points are independent (cv::parallel_for_ over points in calcOpticalFlowPyrLK): one patch buffer per thread */
+#pragma omp parallel
+    {
     int16_t* Iw = (int16_t*)malloc(sizeof(int16_t) * (size_t)ww * wh * 3);
     int16_t* dIw = Iw + (size_t)ww * wh;
-    const float scale = (float)(1. / (1 << level));
-    int i, x, y, j;
-
+    int x, y, j;
+#pragma omp for schedule(dynamic, 16)
     for (i = 0; i < n; i++) {
         float ppx = prev_pts[2 * i] * scale, ppy = prev_pts[2 * i + 1] * scale;
         float npx, npy;
@@ -143,6 +158,7 @@ static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int 
         else { npx = next_pts[2 * i] * 2.f; npy = next_pts[2 * i + 1] * 2.f; }
         next_pts[2 * i] = npx; next_pts[2 * i + 1] = npy;
 
+#pragma omp atomic
         orc_lk_counters[2]++;
         ppx -= half_x; ppy -= half_y;
         int ipx = cv_floor_f(ppx), ipy = cv_floor_f(ppy);
@@ -178,6 +194,7 @@ static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int 
             continue;
         }
         D = 1.f / D;
+#pragma omp atomic
         orc_lk_counters[0]++;
         npx -= half_x; npy -= half_y;
         float pdx = 0.f, pdy = 0.f;
@@ -187,6 +204,7 @@ static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int 
                 if (level == 0) status[i] = 0;
                 break;
             }
+#pragma omp atomic
             orc_lk_counters[1]++;
             a = npx - inx; b = npy - iny;
             iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
@@ -222,6 +240,7 @@ static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int 
         }
     }
     free(Iw);
+    }
 }
 
 void orc_lk_track(const orc_pyramid* prev, const orc_pyramid* next, int n, const float* prev_pts,

@@ -13,8 +13,10 @@
 /* ------------------------------------------------------------------ triangulation (A.4) */
 void orc_triangulate(const float Pl[12], const float Pr[12], int n, const float* pts_l, const float* pts_r,
                      float* xyz, float* homog) {
-    int i, k;
+    int i;
+#pragma omp parallel for
     for (i = 0; i < n; i++) {
+        int k;
         double A[16], W[4], Ut[16], Vt[16];
         double xl = pts_l[2 * i], yl = pts_l[2 * i + 1], xr = pts_r[2 * i], yr = pts_r[2 * i + 1];
         for (k = 0; k < 4; k++) {

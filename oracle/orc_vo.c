@@ -5,8 +5,22 @@
  * (SURVEY.md Appendix B-2, B-3, B-4, B-8, B-9). */
 #include "orc.h"
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
+
+/* worker threads for the data-parallel loops (LK points, image rows); returns the count in effect. n <= 0 = all cores */
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n <= 0) n = omp_get_num_procs();
+    omp_set_num_threads(n);
+    return n;
+#else
+    (void)n; return 1;
+#endif
+}
 
 void orc_config_default(orc_config* c) {
     c->bucket_start_row = 4; c->buckets_along_height = 92; c->buckets_along_width = 160;

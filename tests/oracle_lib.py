@@ -68,11 +68,17 @@ def lib():
         _lib.orc_vo_create.restype = C.c_void_p
         _lib.orc_epnp.restype = C.c_double
         _lib.orc_rng_next.restype = C.c_uint32
+        _lib.orc_set_threads(1)          # deterministic default: single thread (bench.py raises it for the all-cores baseline)
     return _lib
 
 
 def _p(a, t=None):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def set_threads(n):
+    """threads for the oracle's data-parallel loops (n <= 0: all cores); results do not depend on it"""
+    return lib().orc_set_threads(int(n))
 
 
 def default_config(**over):
