@@ -414,3 +414,30 @@ def test_long_sequence_parity_crosses_age_threshold(api):
         prev_ages = fg[1].copy()
     assert max_age >= 20 and dropped_old          # the age gate was really exercised
     assert int(fg[1].max()) <= 20                  # nothing older than the threshold survives a bucketing
+
+
+@pytest.mark.parametrize("seed,step,yaw,win", [(101, 0.25, 0.6, 21), (202, 0.6, 0.2, 10), (303, 0.1, 1.0, 15)])
+def test_soak_sequences_stay_bit_exact(api, seed, step, yaw, win):
+    """40 frames per seed with different speeds / yaw rates / windows, batched 2-wide on the GPU against two oracle
+    instances: ok flags, counters and the whole feature set must match on every frame, poses within tolerance."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=416, height=176, cx=208.0, cy=88.0)
+    seqs = [syn.StereoSequence(cal=cal, n_frames=40, seed=seed + i, step=step, yaw_amp_deg=yaw) for i in range(2)]
+    Pl, Pr = syn.projection_matrices(cal)
+    over = dict(win_w=win, win_h=win, max_translation_norm=2.0)
+    ovos = []
+    for _ in seqs:
+        o = orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl, Pr); ovos.append(o)
+    g = api.BatchVisualOdometry(416, 176, 2, api.default_config(**over)); g.initalize_projection_matricies(Pl, Pr)
+    n_ok = 0
+    for k in range(40):
+        ok, T = g.stereo_callback_batch([s.left[k] for s in seqs], [s.right[k] for s in seqs])
+        for i, o in enumerate(ovos):
+            ok_o, T_o = o.stereo_callback(seqs[i].left[k], seqs[i].right[k])
+            assert ok_o == bool(ok[i]), (k, i)
+            assert {f[0]: getattr(o.stats, f[0]) for f in o.stats._fields_} == g.stats[i].as_dict(), (k, i)
+            fo, fg = o.features(), g.features(i)
+            assert np.array_equal(bits(fo[0]), bits(fg[0])) and np.array_equal(fo[1], fg[1]) and np.array_equal(fo[2], fg[2]), (k, i)
+            assert np.abs(T_o[:3, 3] - T[i][:3, 3]).max() < POSE_TOL_T and rot_angle(T_o[:3, :3], T[i][:3, :3]) < POSE_TOL_R, (k, i)
+            n_ok += int(ok_o)
+    assert n_ok > 40                                    # the sequences really produce poses most of the time
