@@ -47,7 +47,7 @@ typedef struct {
     double circular_matching_success_threshold; /* vo.h:115 0.15 */
     double max_translation_norm;          /* vo.h:121  0.1 */
     double max_rotation_norm;             /* vo.h:127  0.5 */
-    int win_w, win_h;                     /* vo.h:251  10x10 (square windows 3..31) */
+    int win_w, win_h;                     /* vo.h:251  10x10 (square; kernels are instantiated for 7, 10, 15, 21 and 31) */
     int max_level;                        /* vo.h:252  3 */
     int lk_max_count;                     /* vo.cpp:183 30 */
     double lk_epsilon;                    /* vo.cpp:184 1e-4 */
@@ -144,7 +144,7 @@ int svo_append_features_from_image(int device, const svo_config* cfg, const uint
 /* replaces: cv::buildOpticalFlowPyramid(img, pyr, winSize, maxLevel)  (vo.cpp:50,52,200,201).
  * Returns the levels as tightly packed u8 images concatenated in `levels_out` (level l is
  * w_l*h_l bytes, w_l=(w_{l-1}+1)/2); n_levels_out <= max_level+1 (stops when the next level would
- * not exceed the window).  Derivatives are not materialised (they are fused into the LK kernel). */
+ * not exceed the window; win >= 7).  Derivatives are not materialised (they are fused into the LK kernel). */
 int svo_build_pyramid(int device, const uint8_t* img, int w, int h, int stride, int win, int max_level,
                       uint8_t* levels_out, int64_t levels_cap, int* n_levels_out);
 
