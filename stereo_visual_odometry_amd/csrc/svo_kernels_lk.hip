@@ -26,6 +26,9 @@
 #include <stdlib.h>
 
 #define LK_WBITS 14
+#ifndef LK_EPOCH_LOOP
+#define LK_EPOCH_LOOP(G) ((G) >= 32)
+#endif
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -50,68 +53,98 @@ template <int W, int G> struct LkLayout {
     static constexpr int NB = PPL + 1;                // search-window bytes per segment per row
 };
 
-// sum over the G lanes of a feature group; every lane of the group receives the total
+// one doubling step of the in-row DPP reduction (S = 0..3: lane pairs, quads, half rows, rows)
+template <int S>
+__device__ __forceinline__ int dpp_row_step(int v) {
+    if (S == 0) return v + __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    if (S == 1) return v + __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    if (S == 2) return v + __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    return v + __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);               // row_mirror: every lane holds its row's sum
+}
+// rows -> group: every lane of the group ends up with the group total
 template <int G>
-__device__ __forceinline__ int group_sum_i32(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror: every lane holds its row's sum
+__device__ __forceinline__ int dpp_cross_rows(int v) {
     if (G == 64) {
         v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
         v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
         v = __builtin_amdgcn_readlane(v, 63);
     }
-    if (G == 32) {                                                       // two rows per feature: add the partner row's sum
-        const int r0 = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16);
-        const int r1 = __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
-        v = (threadIdx.x & 32) ? r1 : r0;
+    if (G == 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        v = r[0] + r[1];
     }
     return v;
 }
-// exact group-wide sum of int32 partials, as the float the LK code needs: the partial is split into 16-bit halves
-// (each half-sum fits 23 bits).  (float)hi and (float)lo are exact, (float)hi * 65536 is exact (power of two), so the
-// single f32 addition rounds the exact integer sum once, to nearest-even — the same value as (float)(double)(int64 sum).
-template <int G>
-__device__ __forceinline__ float group_sum_to_float(int partial) {
-    const int slo = group_sum_i32<G>(partial & 0xFFFF);
-    const int shi = group_sum_i32<G>(partial >> 16);                  // arithmetic shift: signed high half
-    return (float)shi * 65536.f + (float)slo;
+// Largest per-lane |partial| of PIX window pixels: |diff| <= 255 * 32, |Ix|, |Iy| <= 4080 (Scharr of u8).  PRE = number of
+// doubling steps such a partial survives in int32; the split into 16-bit halves can wait that long.
+constexpr int lk_presplit_steps(int pix) {
+    long long m = (long long)pix * 8160LL * 4080LL;
+    int k = 0;
+    while (k < 4 && m * 2 <= 2147483647LL) { m *= 2; k++; }
+    return k;
 }
-
-// N independent exact sums at once, the DPP steps of the 2N half-sums issued round-robin so every DPP instruction has
+// N independent exact sums at once ("wide" form, any input): the partials are split into 16-bit halves (each half-sum fits
+// 23 bits) after the first PRE steps; the DPP steps of the values are issued round-robin so every DPP instruction has
 // independent work between it and its predecessor (DPP needs 2 wait states after a VALU write of its source).
-template <int G, int N>
+template <int G, int N, int PRE>
 __device__ __forceinline__ void group_sums_to_float(const int (&partial)[N], float (&out)[N]) {
-    int v[2 * N];
+    int u[N], v[2 * N];
 #pragma unroll
-    for (int i = 0; i < N; i++) { v[2 * i] = partial[i] & 0xFFFF; v[2 * i + 1] = partial[i] >> 16; }
+    for (int i = 0; i < N; i++) u[i] = partial[i];
+    if (PRE > 0) {
 #pragma unroll
-    for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0xB1, 0xF, 0xF, true);
-#pragma unroll
-    for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x4E, 0xF, 0xF, true);
-#pragma unroll
-    for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x141, 0xF, 0xF, true);
-#pragma unroll
-    for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x140, 0xF, 0xF, true);
-    if (G == 64) {
-#pragma unroll
-        for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x142, 0xA, 0xF, false);
-#pragma unroll
-        for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x143, 0xC, 0xF, false);
-#pragma unroll
-        for (int i = 0; i < 2 * N; i++) v[i] = __builtin_amdgcn_readlane(v[i], 63);
+        for (int i = 0; i < N; i++) u[i] = dpp_row_step<0>(u[i]);
     }
-    if (G == 32) {
+    if (PRE > 1) {
 #pragma unroll
-        for (int i = 0; i < 2 * N; i++) {
-            const int r0 = __builtin_amdgcn_readlane(v[i], 0) + __builtin_amdgcn_readlane(v[i], 16);
-            const int r1 = __builtin_amdgcn_readlane(v[i], 32) + __builtin_amdgcn_readlane(v[i], 48);
-            v[i] = (threadIdx.x & 32) ? r1 : r0;
-        }
+        for (int i = 0; i < N; i++) u[i] = dpp_row_step<1>(u[i]);
     }
+    if (PRE > 2) {
+#pragma unroll
+        for (int i = 0; i < N; i++) u[i] = dpp_row_step<2>(u[i]);
+    }
+    if (PRE > 3) {
+#pragma unroll
+        for (int i = 0; i < N; i++) u[i] = dpp_row_step<3>(u[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) { v[2 * i] = u[i] & 0xFFFF; v[2 * i + 1] = u[i] >> 16; }
+    if (PRE < 1) {
+#pragma unroll
+        for (int i = 0; i < 2 * N; i++) v[i] = dpp_row_step<0>(v[i]);
+    }
+    if (PRE < 2) {
+#pragma unroll
+        for (int i = 0; i < 2 * N; i++) v[i] = dpp_row_step<1>(v[i]);
+    }
+    if (PRE < 3) {
+#pragma unroll
+        for (int i = 0; i < 2 * N; i++) v[i] = dpp_row_step<2>(v[i]);
+    }
+    if (PRE < 4) {
+#pragma unroll
+        for (int i = 0; i < 2 * N; i++) v[i] = dpp_row_step<3>(v[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) v[i] = dpp_cross_rows<G>(v[i]);
 #pragma unroll
     for (int i = 0; i < N; i++) out[i] = (float)v[2 * i + 1] * 65536.f + (float)v[2 * i];
+}
+// "narrow" form: the caller guarantees that the sum of |terms| stays below 2^31, so every intermediate fits int32 and
+// v_cvt_f32_i32 rounds the exact total once (nearest-even) — the same float as the wide form.
+template <int G, int N>
+__device__ __forceinline__ void group_sums_to_float_narrow(const int (&partial)[N], float (&out)[N]) {
+    int u[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) u[i] = dpp_row_step<0>(partial[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) u[i] = dpp_row_step<1>(u[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) u[i] = dpp_row_step<2>(u[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) u[i] = dpp_row_step<3>(u[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) out[i] = (float)dpp_cross_rows<G>(u[i]);
 }
 
 __device__ __forceinline__ void lk_weights(float a, float b, int& iw00, int& iw01, int& iw10, int& iw11) {
@@ -130,7 +163,15 @@ typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int dot2(unsigned a, unsigned b, int acc) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), acc, false);
 }
+// Same product with the clamp bit set: the operands used here cannot overflow int32, so the result is identical; the bit
+// only makes the compiler pick the three-address encoding (v_dot2_i32_i16 d, a, b, c) instead of copying c for the
+// accumulate-in-place v_dot2c form — used where the addend must stay live.
+__device__ __forceinline__ int dot2_keep(unsigned a, unsigned b, int acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), acc, true);
+}
 __device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
+// low halves of two registers -> one packed pair (one v_perm_b32)
+__device__ __forceinline__ unsigned pack_lo16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
 
 // N bytes at p (any alignment) -> N-1 packed pairs: pair[x] = byte[x] | byte[x+1] << 16 (one v_perm_b32 each)
 template <int N>
@@ -156,6 +197,8 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                         const LkSegs<LkLayout<W, G>::SPL>& sg) {
     using LL = LkLayout<W, G>;
     constexpr int PPL = LL::PPL, EXT = LL::EXT, NS = LL::NS, NB = LL::NB, SPL = LL::SPL;
+    constexpr int PRE = lk_presplit_steps(PPL * SPL);
+    constexpr float NARROW_LIMIT = (float)(0.95 * 4611686018427387904.0 / (8160.0 * 8160.0 * W * W));
     const float half = (W - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
     const int top = g.nlevels - 1;
@@ -185,7 +228,13 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         //   t0(c) = 3*(s[y-1][c] + s[y+1][c]) + 10*s[y][c]      t1(c) = s[y+1][c] - s[y-1][c]
         //   dx(c) = t0(c+1) - t0(c-1)                            dy(c) = 3*(t1(c-1) + t1(c+1)) + 10*t1(c)
         // (all intermediates fit 16 bits: |t0| <= 4080, |dx|, |dy| <= 4080).
-        int Ir[SPL][PPL], Ixr[SPL][PPL], Iyr[SPL][PPL];
+        // Kept for the Newton loop, per owned pixel: Kr = 2^(WBITS-6) - (I << (WBITS-5)), the seed of the bilinear dot product
+        // of the search image, so that (seed + J-dot) >> (WBITS-5) IS the mismatch J - I (the subtrahend is a multiple of the
+        // shift unit, so folding it in is exact); and the derivatives as packed signed 16-bit pairs of adjacent pixels, the
+        // operand layout of v_dot2_i32_i16: one instruction multiplies two mismatches with two derivatives and accumulates.
+        constexpr int NPR = (PPL + 1) / 2;
+        int Kr[SPL][PPL];
+        unsigned Ixp[SPL][NPR], Iyp[SPL][NPR];
         int pA11 = 0, pA12 = 0, pA22 = 0;
         const bool interior = ipx >= 1 && ipx + EXT + 1 < L.w && ipy >= 1 && ipy + W + 1 < L.h;
 #pragma unroll
@@ -246,18 +295,28 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             // patch samples (kept in registers for the Newton loop) + covariance partials.  Segments / pixels outside
             // the window get zero derivative weights: their Ix = Iy = 0, so they contribute exact zeros everywhere.
             const unsigned wd0 = sg.on[k] ? w0 : 0u, wd1 = sg.on[k] ? w1 : 0u;
+            int ixv[PPL], iyv[PPL];
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const bool on = (EXT == W) || (xs + j < W);
-                Ir[k][j] = dot2(Ip[1][j], w1, dot2(Ip[0][j], w0, 1 << (LK_WBITS - 6))) >> (LK_WBITS - 5);
-                int ixval = dot2(DXp[1][j], wd1, dot2(DXp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
-                int iyval = dot2(DYp[1][j], wd1, dot2(DYp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
-                Ixr[k][j] = on ? ixval : 0; Iyr[k][j] = on ? iyval : 0;
-                pA11 += __mul24(Ixr[k][j], Ixr[k][j]); pA12 += __mul24(Ixr[k][j], Iyr[k][j]); pA22 += __mul24(Iyr[k][j], Iyr[k][j]);
+                const int ival = dot2(Ip[1][j], w1, dot2(Ip[0][j], w0, 1 << (LK_WBITS - 6))) >> (LK_WBITS - 5);
+                Kr[k][j] = (1 << (LK_WBITS - 6)) - (ival << (LK_WBITS - 5));
+                const int ixval = dot2(DXp[1][j], wd1, dot2(DXp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
+                const int iyval = dot2(DYp[1][j], wd1, dot2(DYp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
+                ixv[j] = on ? ixval : 0; iyv[j] = on ? iyval : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < NPR; q++) {
+                Ixp[k][q] = (2 * q + 1 < PPL) ? pack_lo16(ixv[2 * q], ixv[2 * q + 1]) : ((unsigned)ixv[2 * q] & 0xFFFFu);
+                Iyp[k][q] = (2 * q + 1 < PPL) ? pack_lo16(iyv[2 * q], iyv[2 * q + 1]) : ((unsigned)iyv[2 * q] & 0xFFFFu);
+                pA11 = dot2(Ixp[k][q], Ixp[k][q], pA11); pA12 = dot2(Ixp[k][q], Iyp[k][q], pA12); pA22 = dot2(Iyp[k][q], Iyp[k][q], pA22);
             }
         }
         float As[3];
-        { const int pa[3] = {pA11, pA12, pA22}; group_sums_to_float<G, 3>(pa, As); }
+        { const int pa[3] = {pA11, pA12, pA22}; group_sums_to_float<G, 3, PRE>(pa, As); }
+        // |sum diff*Ix| <= 8160 * sqrt(W^2 * sum Ix^2) (Cauchy-Schwarz): below 2^31 when sum Ix^2 < 2^62 / (8160^2 W^2); 5 % margin
+        // covers the float rounding of As.  Then the mismatch sums never leave int32 and take the narrow reduction.
+        const bool narrow = As[0] < NARROW_LIMIT && As[2] < NARROW_LIMIT;
         const float A11 = As[0] * FLT_SCALE, A12 = As[1] * FLT_SCALE, A22 = As[2] * FLT_SCALE;
         float Dt = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * W * W);
@@ -267,18 +326,13 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         }
         Dt = 1.f / Dt;
         nx -= half; ny -= half;
-        float pdx = 0.f, pdy = 0.f;
-        // Newton iterations, organised in epochs of constant INTEGER window origin: the search window (two rows of
-        // packed byte pairs per segment) is loaded at the start of an epoch and stays in registers until floor(n) changes.
+        // Newton iterations.  The search window (two rows of packed byte pairs per segment) lives in registers and is
+        // re-loaded only when the INTEGER window origin floor(n) changes; most iterations move the window by a fraction of
+        // a pixel and touch no memory.
         int j = 0;
-        bool stop = crit.max_count <= 0;
-        while (!stop) {
-            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
-            if (inx < -W || inx >= L.w || iny < -W || iny >= L.h) {
-                if (level == 0) status = 0;
-                break;
-            }
-            unsigned P0[SPL][PPL], P1[SPL][PPL];
+        float pdx = 0.f, pdy = 0.f;
+        unsigned P0[SPL][PPL], P1[SPL][PPL];
+        auto load_window = [&](int inx, int iny) __attribute__((always_inline)) {
             if (inx >= 0 && inx + EXT < L.w && iny >= 0 && iny + W < L.h) {
 #pragma unroll
                 for (int k = 0; k < SPL; k++) {
@@ -300,35 +354,82 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                     for (int c = 0; c < PPL; c++) { P0[k][c] = pack16(jb[0][c], jb[0][c + 1]); P1[k][c] = pack16(jb[1][c], jb[1][c + 1]); }
                 }
             }
-            const float fx0 = (float)inx, fy0 = (float)iny;
-            for (;;) {
-                lk_weights(nx - fx0, ny - fy0, iw00, iw01, iw10, iw11);
-                w0 = pack16(iw00, iw01); w1 = pack16(iw10, iw11);
-                int pb1 = 0, pb2 = 0;
+        };
+        // one Newton step against the window loaded at integer origin (fx0, fy0); returns true when the track is finished
+        auto newton_step = [&](float fx0, float fy0) __attribute__((always_inline)) -> bool {
+            lk_weights(nx - fx0, ny - fy0, iw00, iw01, iw10, iw11);
+            w0 = pack16(iw00, iw01); w1 = pack16(iw10, iw11);
+            int pb1 = 0, pb2 = 0;
 #pragma unroll
-                for (int k = 0; k < SPL; k++)
+            for (int k = 0; k < SPL; k++) {
+                int dv[PPL];
+                // J - I, |.| <= 8160; three sweeps so that dependent dot instructions are PPL instructions apart
 #pragma unroll
-                    for (int jj = 0; jj < PPL; jj++) {
-                        // masked pixels have Ix = Iy = 0, so whatever diff they see contributes an exact zero
-                        int diff = (dot2(P1[k][jj], w1, dot2(P0[k][jj], w0, 1 << (LK_WBITS - 6))) >> (LK_WBITS - 5)) - Ir[k][jj];
-                        pb1 += __mul24(diff, Ixr[k][jj]); pb2 += __mul24(diff, Iyr[k][jj]);
-                    }
-                float bs[2];
-                { const int pb[2] = {pb1, pb2}; group_sums_to_float<G, 2>(pb, bs); }
-                const float b1 = bs[0] * FLT_SCALE, b2 = bs[1] * FLT_SCALE;
-                const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
-                nx += dx; ny += dy;
-                outx = nx + half; outy = ny + half;
-                if ((double)dx * (double)dx + (double)dy * (double)dy <= crit.eps2) { stop = true; break; }
-                // "(double)|v| < 0.01" for a float v is exactly "|v| < nextafterf((float)0.01)": 0.01 lies between the floats
-                // 0x3C23D70A and 0x3C23D70B, so v < 0.01 (as doubles) <=> v <= 0x3C23D70A <=> v < 0x3C23D70B
-                if (j > 0 && fabsf(dx + pdx) < 0.010000000707805157f && fabsf(dy + pdy) < 0.010000000707805157f) {
-                    outx -= dx * 0.5f; outy -= dy * 0.5f;
-                    stop = true; break;
+                for (int jj = 0; jj < PPL; jj++) dv[jj] = dot2_keep(P0[k][jj], w0, Kr[k][jj]);
+#pragma unroll
+                for (int jj = 0; jj < PPL; jj++) dv[jj] = dot2(P1[k][jj], w1, dv[jj]);
+#pragma unroll
+                for (int jj = 0; jj < PPL; jj++) dv[jj] >>= (LK_WBITS - 5);
+#pragma unroll
+                for (int q = 0; q < NPR; q++) {
+                    // masked pixels (and the unpaired upper half) have Ix = Iy = 0: whatever mismatch they see contributes an exact zero
+                    const unsigned dp = (2 * q + 1 < PPL) ? pack_lo16(dv[2 * q], dv[2 * q + 1]) : (unsigned)dv[2 * q];
+                    pb1 = dot2(dp, Ixp[k][q], pb1); pb2 = dot2(dp, Iyp[k][q], pb2);
                 }
-                pdx = dx; pdy = dy;
-                if (++j >= crit.max_count) { stop = true; break; }
-                if ((int)floorf(nx) != inx || (int)floorf(ny) != iny) break;       // integer origin moved: new epoch
+            }
+            float bs[2];
+            {
+                const int pb[2] = {pb1, pb2};
+                if (narrow) group_sums_to_float_narrow<G, 2>(pb, bs);
+                else group_sums_to_float<G, 2, PRE>(pb, bs);
+            }
+            const float b1 = bs[0] * FLT_SCALE, b2 = bs[1] * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
+            nx += dx; ny += dy;
+            outx = nx + half; outy = ny + half;
+            if ((double)dx * (double)dx + (double)dy * (double)dy <= crit.eps2) return true;
+            // "(double)|v| < 0.01" for a float v is exactly "|v| < nextafterf((float)0.01)": 0.01 lies between the floats
+            // 0x3C23D70A and 0x3C23D70B, so v < 0.01 (as doubles) <=> v <= 0x3C23D70A <=> v < 0x3C23D70B
+            if (j > 0 && fabsf(dx + pdx) < 0.010000000707805157f && fabsf(dy + pdy) < 0.010000000707805157f) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                return true;
+            }
+            pdx = dx; pdy = dy;
+            return ++j >= crit.max_count;
+        };
+        if (LK_EPOCH_LOOP(G)) {
+            // one or two features per wave: epochs of constant integer origin, the inner loop is pure register arithmetic
+            // (measured on MI355X, LK chain ms for 32 sequences, epoch / flat: W=21 G=64 2.12 / 2.42, W=15 G=32 1.48 / 1.55)
+            bool stop = crit.max_count <= 0;
+            while (!stop) {
+                const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+                if (inx < -W || inx >= L.w || iny < -W || iny >= L.h) {
+                    if (level == 0) status = 0;
+                    break;
+                }
+                load_window(inx, iny);
+                const float fx0 = (float)inx, fy0 = (float)iny;
+                for (;;) {
+                    if (newton_step(fx0, fy0)) { stop = true; break; }
+                    if ((int)floorf(nx) != inx || (int)floorf(ny) != iny) break;       // integer origin moved: new epoch
+                }
+            }
+        } else {
+            // four features per wave: one flat loop, the groups reload independently under the exec mask while the
+            // arithmetic of the iteration stays converged (W=10 G=16: 1.05 flat / 1.10 epoch, W=7: 0.77 / 0.83)
+            bool run = crit.max_count > 0;
+            int inx = -0x40000000, iny = -0x40000000;
+            while (run) {
+                const int cx = (int)floorf(nx), cy = (int)floorf(ny);
+                if (cx != inx || cy != iny) {
+                    inx = cx; iny = cy;
+                    if (inx < -W || inx >= L.w || iny < -W || iny >= L.h) {
+                        if (level == 0) status = 0;
+                        break;
+                    }
+                    load_window(inx, iny);
+                }
+                if (newton_step((float)inx, (float)iny)) break;
             }
         }
         // flags = 0 with err != NULL (vo.cpp:182,203): the level-0 error block re-checks the final window origin
@@ -455,9 +556,9 @@ __global__ __launch_bounds__(64) void k_lk_single(DevBuffers d, int slotA, int c
 
 #define LK_MAX_GRID 16384
 static int lk_xcd_mapping() { static int v = -1; if (v < 0) { const char* e = getenv("SVO_LK_XCD"); v = e ? atoi(e) : 0; } return v; }
-// window -> lanes per feature, chosen by measurement on MI355X (32 sequences, LK chain ms): W=10: G=16 1.05 vs G=64 1.26;
-// W=15: 1.81 vs 1.55; W=21: 2.74 (G=16) / 2.33 (G=32) / 2.04 (G=64).  Small windows: one DPP row per feature, 4 per wave.
-#define LK_FOR_EACH_WINDOW(X) X(7, 16) X(10, 16) X(15, 64) X(21, 64) X(31, 64)
+// (window, lanes per feature) instantiations; the FIRST entry of a window is its default, the others are selectable with
+// SVO_LK_G=<lanes> for measurement.
+#define LK_FOR_EACH_WINDOW(X) X(7, 16) X(10, 16) X(15, 32) X(15, 64) X(21, 64) X(21, 32) X(31, 64)
 
 bool lk_window_supported(int win) {
 #define CHK(Wn, Gn) if (win == Wn) return true;
@@ -465,11 +566,21 @@ bool lk_window_supported(int win) {
 #undef CHK
     return false;
 }
+static int lk_group_for(int win) {
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("SVO_LK_G"); env = e ? atoi(e) : 0; }
+    int def = 0; bool have_env = false;
+#define CHK(Wn, Gn) if (win == Wn) { if (!def) def = Gn; if (env == Gn) have_env = true; }
+    LK_FOR_EACH_WINDOW(CHK)
+#undef CHK
+    return have_env ? env : def;
+}
 
 void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
     if (grid_n < 1) grid_n = 1;
     if (grid_n > d.CAP) grid_n = d.CAP;
-#define LAUNCH(Wn, Gn) if (d.cfg.win_w == Wn) { int gx = (grid_n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
+    const int G = lk_group_for(d.cfg.win_w);
+#define LAUNCH(Wn, Gn) if (d.cfg.win_w == Wn && G == Gn) { int gx = (grid_n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
         const int rounds = (d.B + 7) / 8; \
         if (lk_xcd_mapping() == 1) hipLaunchKernelGGL((k_lk_chain<Wn, Gn>), dim3((unsigned)gx * 8u * (unsigned)rounds), dim3(64), 0, st, d, gx); \
         else hipLaunchKernelGGL((k_lk_chain<Wn, Gn>), dim3((unsigned)gx * (unsigned)d.B), dim3(64), 0, st, d, -gx); \
@@ -481,7 +592,8 @@ void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
 void launch_lk_single(const DevBuffers& d, int slotA, int camA, int slotB, int camB, int n, const float2* prev, float2* next,
                       uint8_t* status, hipStream_t st) {
     if (n <= 0) return;
-#define LAUNCH(Wn, Gn) if (d.cfg.win_w == Wn) { int gx = (n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
+    const int G = lk_group_for(d.cfg.win_w);
+#define LAUNCH(Wn, Gn) if (d.cfg.win_w == Wn && G == Gn) { int gx = (n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
         hipLaunchKernelGGL((k_lk_single<Wn, Gn>), dim3(gx), dim3(64), 0, st, d, slotA, camA, slotB, camB, n, prev, next, status); return; }
     LK_FOR_EACH_WINDOW(LAUNCH)
 #undef LAUNCH
