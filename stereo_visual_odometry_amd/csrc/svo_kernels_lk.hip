@@ -170,6 +170,8 @@ __device__ __forceinline__ int dot2_keep(unsigned a, unsigned b, int acc) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), acc, true);
 }
 __device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
+// (upper half of a, lower half of b) as one packed pair
+__device__ __forceinline__ unsigned hi_lo16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040302u); }
 // low halves of two registers -> one packed pair (one v_perm_b32)
 __device__ __forceinline__ unsigned pack_lo16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
 
@@ -209,7 +211,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         const LevelInfo L = g.lv[level];
         const uint8_t* __restrict__ A = pyrA + L.off;
         const uint8_t* __restrict__ Bm = pyrB + L.off;
-        const float scale = 1.f / (float)(1 << level);
+        const float scale = __int_as_float((127 - level) << 23);            // 2^-level, exact (= 1.f / (1 << level))
         float ppx = px * scale, ppy = py * scale;
         if (level == top) { nx = ppx; ny = ppy; } else { nx = outx * 2.f; ny = outy * 2.f; }
         outx = nx; outy = ny;
@@ -248,12 +250,20 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 for (int r = 0; r < 4; r++) load_pairs<NS>(p + (size_t)r * L.w, Q[r]);
 #pragma unroll
                 for (int yy = 0; yy < 2; yy++) {
+                    // the vertical passes are evaluated on the EVEN pairs (columns 2i, 2i+1); an odd pair is the upper half of
+                    // its left neighbour next to the lower half of its right one — one v_perm instead of recomputing both columns
                     ushort2v T0[NS - 1]; short2v T1[NS - 1];
 #pragma unroll
                     for (int c = 0; c < NS - 1; c++) {
+                        if ((c & 1) && c + 1 < NS - 1) continue;
                         const ushort2v q0 = __builtin_bit_cast(ushort2v, Q[yy][c]), q1 = __builtin_bit_cast(ushort2v, Q[yy + 1][c]), q2 = __builtin_bit_cast(ushort2v, Q[yy + 2][c]);
                         T0[c] = (q0 + q2) * (unsigned short)3 + q1 * (unsigned short)10;
                         T1[c] = __builtin_bit_cast(short2v, (ushort2v)(q2 - q0));
+                    }
+#pragma unroll
+                    for (int c = 1; c + 1 < NS - 1; c += 2) {
+                        T0[c] = __builtin_bit_cast(ushort2v, hi_lo16(__builtin_bit_cast(unsigned, T0[c - 1]), __builtin_bit_cast(unsigned, T0[c + 1])));
+                        T1[c] = __builtin_bit_cast(short2v, hi_lo16(__builtin_bit_cast(unsigned, T1[c - 1]), __builtin_bit_cast(unsigned, T1[c + 1])));
                     }
 #pragma unroll
                     for (int x = 0; x < PPL; x++) {
@@ -299,8 +309,8 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const bool on = (EXT == W) || (xs + j < W);
-                const int ival = dot2(Ip[1][j], w1, dot2(Ip[0][j], w0, 1 << (LK_WBITS - 6))) >> (LK_WBITS - 5);
-                Kr[k][j] = (1 << (LK_WBITS - 6)) - (ival << (LK_WBITS - 5));
+                const int iacc = dot2(Ip[1][j], w1, dot2(Ip[0][j], w0, 1 << (LK_WBITS - 6)));          // I = iacc >> (WBITS-5)
+                Kr[k][j] = (1 << (LK_WBITS - 6)) - (iacc & ~((1 << (LK_WBITS - 5)) - 1));
                 const int ixval = dot2(DXp[1][j], wd1, dot2(DXp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
                 const int iyval = dot2(DYp[1][j], wd1, dot2(DYp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
                 ixv[j] = on ? ixval : 0; iyv[j] = on ? iyval : 0;
