@@ -474,27 +474,33 @@ __device__ __forceinline__ LkCrit make_crit(const svo_config& c) {
 }
 
 // ---- fused circular matching: L0 -> L1 -> R1 -> R0 -> L0 + masks (vo.cpp:203-230, 341-359) ----
-// Block -> (sequence, feature) mapping, two forms (launch argument `slots` > 0 / < 0):
-//  * plain (default): sequence-major, one block per feature, every sequence spread over all XCDs.
-//  * XCD-affine (SVO_LK_XCD=1): workgroups are dealt round-robin over the 8 XCDs (block b lands on XCD b % 8,
-//    MI355X_MICROARCH.md; used for speed only), each XCD has a private 4 MiB L2 and one sequence's four pyramids are
-//    2.5 MB, so XCD x is given the sequences x, x+8, ... and walks through them one at a time.
-// Measured on MI355X, 32 sequences per launch (rocprofv3 FETCH_SIZE, HIP-event time): plain 334 MB / 2.10 ms;
-// XCD-affine 39 MB / 2.26 ms (dispatch is in global block order and stalls on the busiest XCD); a persistent variant
-// pulling from per-XCD work queues (HW_REG_XCC_ID + atomicAdd, with stealing) 45 MB / 2.44 ms.  The kernel is
-// VALU-issue-bound and the extra fetches of the plain form are served by the Infinity Cache, so the fastest form is
-// the default and the affine one stays selectable for HBM-constrained deployments.
+// Block -> (sequence, feature group) mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b lands on XCD
+// b % 8, MI355X_MICROARCH.md; used for speed only, never for correctness) and every XCD has a private 4 MiB L2; one
+// sequence's four pyramids are 2.5 MB and 2-3 sequences are in flight at any time.  Three forms (launch argument `mode`):
+//  * LK_MAP_STRIPE (default): sequence-major, `slots` blocks per sequence; XCD x takes runs of `chunk` consecutive
+//    feature groups, cyclically (run q of XCD x = groups (8q + x) * chunk ...).  Features are in bucket raster order, so
+//    a run is a short horizontal strip of the image whose windows share cache lines, and every XCD touches a fraction of
+//    each pyramid instead of all of it.  The runs must stay short: work per feature is spatially correlated and the
+//    dispatcher is in-order, so long runs unbalance the XCDs.
+//  * LK_MAP_INTERLEAVED (= chunk 1): every XCD sees every 8th feature, i.e. the whole image.
+//  * LK_MAP_AFFINE (SVO_LK_XCD=1): XCD x is given the sequences x, x+8, ... and walks through them one at a time.
+// Measured on MI355X, 32 sequences per launch (rocprofv3 FETCH_SIZE per launch / HIP-event time):
+//   chunk 1: 340 MB / 1.90 ms    4: 214 / 1.91    16: 174 / 1.94    64: 118 / 2.18    whole eighths: 61 / 2.79
+//   affine: 39 MB / 2.02 ms.  The kernel is VALU-bound and the fetches are served by the Infinity Cache, so the default
+//   (SVO_LK_CHUNK=8) takes the traffic reduction that is free; the others stay selectable.
+#define LK_MAP_STRIPE 0
+#define LK_MAP_AFFINE 1
+#define LK_MAP_INTERLEAVED 2
 template <int W, int G>
-__global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots) {
-    constexpr int FPW = 64 / G;                                       // features per wave
+__global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mode, int chunk) {
+    constexpr int FPW = 64 / G;                                       // features per wave (= per block)
     int seq, fb;
-    if (slots > 0) {
+    if (mode == LK_MAP_AFFINE) {
         const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
         const int jr = t / slots;                                     // round of sequences on this XCD
         fb = t - jr * slots;                                          // feature block
         seq = jr * 8 + xcd;
-    } else {                                                          // plain mapping: sequence-major
-        slots = -slots;
+    } else {
         seq = blockIdx.x / slots; fb = blockIdx.x - seq * slots;
     }
     if (seq >= d.B) return;
@@ -513,8 +519,21 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots) {
     LkSegs<LkLayout<W, G>::SPL> sg;
     lk_segments<W, G>(sg);
     const int slot = threadIdx.x / G;
-    for (int base = fb * FPW; base < n; base += slots * FPW) {
-        const int idx = base + slot;
+    const int ngroups = (n + FPW - 1) / FPW;                          // feature groups (one block's worth) in this sequence
+    for (int gbase = 0; gbase < ngroups; gbase += slots) {
+        int grp;
+        if (mode == LK_MAP_STRIPE) {
+            const int ng = min(slots, ngroups - gbase);              // groups handled in this round by the sequence's blocks
+            const int x = fb & 7, r = fb >> 3;                       // slots % 8 == 0, so fb & 7 == blockIdx.x & 7 == the XCD
+            const int q = r / chunk;                                 // the r-th block of XCD x works in that XCD's q-th run
+            grp = (q * 8 + x) * chunk + (r - q * chunk);
+            if (grp >= ng) break;
+            grp += gbase;
+        } else {
+            grp = gbase + fb;
+            if (grp >= ngroups) break;
+        }
+        const int idx = grp * FPW + slot;
         if (idx >= n) continue;                                       // whole group idle (group-uniform)
         const size_t o = (size_t)seq * d.CAP + idx;
         const float2 p0 = d.feat_xy[s.feat_buf][o];                  // pointsLeftT0 = currentVOFeatures.points (vo.cpp:338)
@@ -565,6 +584,7 @@ __global__ __launch_bounds__(64) void k_lk_single(DevBuffers d, int slotA, int c
 }
 
 #define LK_MAX_GRID 16384
+static int lk_chunk() { static int v = -1; if (v < 0) { const char* e = getenv("SVO_LK_CHUNK"); v = e ? atoi(e) : 8; if (v < 1) v = 1; if (v > 2048) v = 2048; } return v; }
 static int lk_xcd_mapping() { static int v = -1; if (v < 0) { const char* e = getenv("SVO_LK_XCD"); v = e ? atoi(e) : 0; } return v; }
 // (window, lanes per feature) instantiations; the FIRST entry of a window is its default, the others are selectable with
 // SVO_LK_G=<lanes> for measurement.
@@ -590,10 +610,13 @@ void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
     if (grid_n < 1) grid_n = 1;
     if (grid_n > d.CAP) grid_n = d.CAP;
     const int G = lk_group_for(d.cfg.win_w);
+    const int mode = lk_xcd_mapping();
 #define LAUNCH(Wn, Gn) if (d.cfg.win_w == Wn && G == Gn) { int gx = (grid_n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
+        const int chunk = lk_chunk(); \
+        gx = (gx + 8 * chunk - 1) / (8 * chunk) * (8 * chunk);   /* blocks per sequence: whole runs on every XCD */ \
         const int rounds = (d.B + 7) / 8; \
-        if (lk_xcd_mapping() == 1) hipLaunchKernelGGL((k_lk_chain<Wn, Gn>), dim3((unsigned)gx * 8u * (unsigned)rounds), dim3(64), 0, st, d, gx); \
-        else hipLaunchKernelGGL((k_lk_chain<Wn, Gn>), dim3((unsigned)gx * (unsigned)d.B), dim3(64), 0, st, d, -gx); \
+        const unsigned blocks = mode == LK_MAP_AFFINE ? (unsigned)gx * 8u * (unsigned)rounds : (unsigned)gx * (unsigned)d.B; \
+        hipLaunchKernelGGL((k_lk_chain<Wn, Gn>), dim3(blocks), dim3(64), 0, st, d, gx, mode, chunk); \
         return; }
     LK_FOR_EACH_WINDOW(LAUNCH)
 #undef LAUNCH
