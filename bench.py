@@ -203,6 +203,8 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as orc
 
+            cpu_T = {}                                        # step -> 4x4 the oracle returned (slot 0 sees the same frame stream)
+
             def cpu_rate(threads, frames):
                 used = orc.set_threads(threads)
                 o = orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl, Pr)
@@ -211,7 +213,7 @@ def main():
                 c0 = time.perf_counter()
                 for i in range(1, frames + 1):
                     f = ping_pong(i)
-                    o.stereo_callback(sq.left[f], sq.right[f])
+                    cpu_T[i] = o.stereo_callback(sq.left[f], sq.right[f])[1]
                 return frames / (time.perf_counter() - c0), used
 
             single, _ = cpu_rate(1, max(4, args.cpu_frames // 3))
@@ -220,8 +222,21 @@ def main():
             cpu = {"value": allc, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
                    "sample": "%d frame pairs of the same 1241x376 synthetic sequence through oracle/ (plain C -O2, OpenMP over the points "
                              "of each LK pass and over image rows, %d threads); single thread: %.2f frame-pairs/s" % (args.cpu_frames, cores, single)}
+        # ATE (the second half of BASELINE.json's metric), outside the timed region: slot 0's pose stream over the timed steps,
+        # integrated as frame_pose = frame_pose * T (main.cpp:396), against the renderer's ground truth for the same frame
+        # transitions and against the CPU oracle on the steps its bounded sample covers
+        first = args.warmup + 1
+        est = [poses[0, c, :16].reshape(4, 4) for c in range(args.steps)]
+        gt = [np.linalg.inv(pool[0].poses[ping_pong(first + c - 1)]) @ pool[0].poses[ping_pong(first + c)] for c in range(args.steps)]
+        ate = {"vs_ground_truth_m": syn.ate_rmse(syn.integrate(est), syn.integrate(gt)), "frames": args.steps,
+               "path_length_m": float(sum(np.linalg.norm(g[:3, 3]) for g in gt)), "vs_cpu_oracle_m": None, "oracle_frames": 0}
+        if cpu is not None:
+            common = [c for c in range(args.steps) if (first + c) in cpu_T]
+            if common:
+                ate["vs_cpu_oracle_m"] = syn.ate_rmse(syn.integrate([est[c] for c in common]), syn.integrate([cpu_T[first + c] for c in common]))
+                ate["oracle_frames"] = len(common)
         out = {
-            "metric": "stereo frame-pairs/sec on KITTI-00 1241x376 @2k feats", "value": value, "unit": "frame-pairs/s",
+            "metric": "stereo frame-pairs/sec on KITTI-00 1241x376 @2k feats; ATE vs ref", "value": value, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int64/f32 (LK), f64 (PnP)",
             "data": "synthetic",
@@ -233,7 +248,7 @@ def main():
                          "algorithmic_bytes_per_frame_pair": {"lk_chain": bytes_lk, "whole_frame": bytes_total},
                          "kernel_avg_ms": lk_avg_ms, "frame_avg_ms": float(np.mean(fr_ms)),
                          "whole_frame_frac": bytes_total * value / world / 1e9 / PEAK_HBM_GBS},
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu, "ate": ate,
         }
         print(json.dumps(out))
     if world > 1:
