@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic sequences rendered per rank")
     ap.add_argument("--frames", type=int, default=10, help="frames rendered per pool sequence (ping-pong replay)")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg5"],
+                    help="BASELINE.json configs[1] (the metric's configuration, default) / configs[2] / configs[4]; the others are extra measurements")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
@@ -97,12 +99,21 @@ def main():
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")     # where collective payloads live
 
     # ---- workload: BASELINE.json configs[1] — KITTI-00 shaped 1241x376, ~2000 FAST features, LK 21x21, maxLevel 3
-    cal = syn.KITTI00
-    W, H = cal["width"], cal["height"]
     win = int(os.environ.get("SVO_BENCH_WIN", "21"))
-    over = dict(win_w=win, win_h=win, max_level=3, ransac_iterations=100, max_translation_norm=2.0)
+    WL = {   # calibration, scene parameters, config overrides, description
+        "cfg2": (syn.KITTI00, dict(seed=0x5EED0002, step=0.5, cell_px=17.6), dict(max_level=3, ransac_iterations=100),
+                 "BASELINE configs[1]: KITTI-00 calibration, 1241x376, LK 21x21 win, maxLevel 3, 100 RANSAC-PnP iterations"),
+        "cfg3": (syn.KITTI00, dict(seed=0x5EED0003, step=0.5, cell_px=12.0), dict(max_level=4, ransac_iterations=1000),
+                 "BASELINE configs[2]: KITTI-00 calibration, 1241x376, ~4000 features, LK 21x21 win, maxLevel 4, 1000 RANSAC-PnP iterations"),
+        "cfg5": (syn.ZED, dict(seed=0x5EED0005, step=0.2, cell_px=14.0, depth=(6.0, 40.0)), dict(max_level=3, ransac_iterations=100),
+                 "BASELINE configs[4]: ZED calibration, 1920x1080, ~8000 features, LK 21x21 win, maxLevel 3, 100 RANSAC-PnP iterations"),
+    }
+    cal, scene, cfg_over, workload_name = WL[args.workload]
+    W, H = cal["width"], cal["height"]
+    over = dict(win_w=win, win_h=win, max_translation_norm=2.0, **cfg_over)
     B, F = args.seqs, args.frames
-    pool = [syn.StereoSequence(cal=cal, n_frames=F, seed=0x5EED0002 + 97 * rank + g, step=0.5, cell_px=17.6)
+    seed0 = scene.pop("seed")
+    pool = [syn.StereoSequence(cal=cal, n_frames=F, seed=seed0 + 97 * rank + g, **scene)
             for g in range(args.pool)]
     left = torch.stack([torch.from_numpy(np.stack(s.left)) for s in pool]).to(dev)      # (G, F, H, W) u8, resident in HBM
     right = torch.stack([torch.from_numpy(np.stack(s.right)) for s in pool]).to(dev)
@@ -183,7 +194,7 @@ def main():
         if world > 1:                                         # rank 0 now holds every sequence's pose stream
             assert len(gathered) == world and all(tuple(g.shape) == (B, args.steps, 17) for g in gathered)
         N = float(np.mean(n_lk))
-        bytes_total, bytes_lk = algorithmic_bytes(W, H, N, 21, 3, 100)
+        bytes_total, bytes_lk = algorithmic_bytes(W, H, N, win, over["max_level"], over["ransac_iterations"])
         lk_avg_ms = float(np.mean(lk_ms))
         achieved = bytes_lk * Bc / (lk_avg_ms * 1e-3) / 1e9    # algorithmic GB/s of the dominant kernel: one launch covers Bc sequences
         value = world * B * args.steps / dt
@@ -240,10 +251,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int64/f32 (LK), f64 (PnP)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: KITTI-00 calibration, 1241x376, LK 21x21 win, maxLevel 3, 100 RANSAC-PnP iterations",
+            "config": {"workload": workload_name,
                        "sequences_per_gpu": B, "contexts_per_gpu": C, "frames_in_flight": depth, "mean_features_into_lk": N,
                        "pose_ok_fraction": n_ok_all / float(world * B * args.steps)},
-            "roofline": {"bound": "hbm", "kernel": "k_lk_chain<21>", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_lk_chain<%d>" % win, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_frame_pair": {"lk_chain": bytes_lk, "whole_frame": bytes_total},
                          "kernel_avg_ms": lk_avg_ms, "frame_avg_ms": float(np.mean(fr_ms)),
