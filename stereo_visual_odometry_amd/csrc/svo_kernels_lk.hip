@@ -26,8 +26,9 @@
 #include <stdlib.h>
 
 #define LK_WBITS 14
-#ifndef LK_EPOCH_LOOP
-#define LK_EPOCH_LOOP(G) ((G) >= 32)
+// Newton-loop form per lanes-per-feature: 0 = epochs, 1 = flat
+#ifndef LK_LOOP_FORM
+#define LK_LOOP_FORM(G) ((G) >= 32 ? 0 : 1)
 #endif
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
@@ -407,7 +408,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             pdx = dx; pdy = dy;
             return ++j >= crit.max_count;
         };
-        if (LK_EPOCH_LOOP(G)) {
+        if (LK_LOOP_FORM(G) == 0) {
             // one or two features per wave: epochs of constant integer origin, the inner loop is pure register arithmetic
             // (measured on MI355X, LK chain ms for 32 sequences, epoch / flat: W=21 G=64 2.12 / 2.42, W=15 G=32 1.48 / 1.55)
             bool stop = crit.max_count <= 0;
@@ -426,7 +427,9 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             }
         } else {
             // four features per wave: one flat loop, the groups reload independently under the exec mask while the
-            // arithmetic of the iteration stays converged (W=10 G=16: 1.05 flat / 1.10 epoch, W=7: 0.77 / 0.83)
+            // arithmetic of the iteration stays converged (W=10 G=16: 1.05 flat / 1.10 epoch, W=7: 0.77 / 0.83).  A third form,
+            // wave-wide epochs left by a ballot as soon as any group's origin moves, cost registers (W=21 G=64: 131 vs 112
+            // VGPRs, 4 -> 3 waves per SIMD) and was slower everywhere (W=21 G=32: 2.29 ms vs 2.03 for the epoch form).
             bool run = crit.max_count > 0;
             int inx = -0x40000000, iny = -0x40000000;
             while (run) {
