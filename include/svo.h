@@ -174,8 +174,9 @@ int svo_camera_to_world(int device, const float K[9], int n, const float* cam_pt
                         double R[9], double t[3], int* inliers, int* n_inliers, int* success,
                         int ransac_iterations, float reproj_error, float confidence, int* iters_run);
 
-/* replaces: getInverseTransform(rotation, translation)  (vo.h:469-470, vo.cpp:246-258). Host-side closed form. */
-int svo_inverse_transform(const double R[9], const double t[3], double T[16]);
+/* replaces: getInverseTransform(rotation, translation)  (vo.h:469-470, vo.cpp:246-258): [R t; 0 1]^-1, 4x4 row-major.
+ * Runs the device function the frame pipeline ends with (one tiny launch). */
+int svo_inverse_transform(int device, const double R[9], const double t[3], double T[16]);
 
 #ifdef __cplusplus
 }

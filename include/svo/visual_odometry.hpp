@@ -152,7 +152,7 @@ inline std::pair<std::vector<int>, bool> cameraToWorld(const Mat33f& cameraProje
 
 inline Mat44 getInverseTransform(const Mat33d& rotation, const Vec3d& translation_stereo) {                     // vo.h:469-470
     Mat44 T;
-    svo_throw(svo_inverse_transform(rotation.data(), translation_stereo.data(), T.data()));
+    svo_throw(svo_inverse_transform(default_device(), rotation.data(), translation_stereo.data(), T.data()));
     return T;
 }
 

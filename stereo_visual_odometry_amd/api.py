@@ -94,12 +94,12 @@ def cameraToWorld(cameraProjection, cameraPoints, worldPoints, rotation, transla
     return (inl[:nin.value].copy(), bool(ok.value)), R.reshape(3, 3), t.reshape(3, 1), iters.value
 
 
-def getInverseTransform(rotation, translation):
+def getInverseTransform(rotation, translation, device=0):
     """vo.h:469-470"""
     R = np.ascontiguousarray(rotation, np.float64).reshape(9)
     t = np.ascontiguousarray(translation, np.float64).reshape(3)
     T = np.zeros(16)
-    check(lib.svo_inverse_transform(ptr(R), ptr(t), ptr(T)))
+    check(lib.svo_inverse_transform(device, ptr(R), ptr(t), ptr(T)))
     return T.reshape(4, 4)
 
 

@@ -102,6 +102,7 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     if (device < 0 || device >= ndev) return fail_arg("no such HIP device");
     HIPCHK(hipSetDevice(device));
     svo_context* c = new svo_context();
+    struct Undo { svo_context* c; ~Undo() { if (c) svo_destroy(c); } } undo{c};     // every early return below frees what exists so far
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     DevBuffers& d = c->d;
@@ -146,6 +147,7 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     }
     HIPCHK(hipMemcpyAsync(d.st, hs.data(), sizeof(SeqState) * B, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    undo.c = nullptr;
     *out = c;
     return SVO_OK;
 }
@@ -156,20 +158,21 @@ extern "C" int svo_create(const svo_config* cfg, int device, int n_seq, int widt
 
 extern "C" void svo_destroy(svo_context* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    for (void* p : c->allocs) hipFree(p);
-    if (c->staging) hipFree(c->staging);
-    if (c->h_staging) hipHostFree(c->h_staging);
-    if (c->h_results) hipHostFree(c->h_results);
-    if (c->h_ptrs) hipHostFree((void*)c->h_ptrs);
+    // teardown is best effort: errors here have nowhere to go, the calls are (void)ed on purpose
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->staging) (void)hipFree(c->staging);
+    if (c->h_staging) (void)hipHostFree(c->h_staging);
+    if (c->h_results) (void)hipHostFree(c->h_results);
+    if (c->h_ptrs) (void)hipHostFree((void*)c->h_ptrs);
     for (int i = 0; i < SVO_RING; i++) {
-        if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]);
-        if (c->ev_f0[i]) hipEventDestroy(c->ev_f0[i]);
-        if (c->ev_lk0[i]) hipEventDestroy(c->ev_lk0[i]);
-        if (c->ev_lk1[i]) hipEventDestroy(c->ev_lk1[i]);
+        if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
+        if (c->ev_f0[i]) (void)hipEventDestroy(c->ev_f0[i]);
+        if (c->ev_lk0[i]) (void)hipEventDestroy(c->ev_lk0[i]);
+        if (c->ev_lk1[i]) (void)hipEventDestroy(c->ev_lk1[i]);
     }
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -353,7 +356,7 @@ extern "C" int svo_get_last_tracks(svo_context* c, int seq, int cap, float* pl0,
 // ================================================================================================
 struct DevTmp {                                   // RAII-ish scratch allocations for the stage calls
     std::vector<void*> p;
-    ~DevTmp() { for (void* q : p) hipFree(q); }
+    ~DevTmp() { for (void* q : p) (void)hipFree(q); }
     template <typename T> hipError_t get(T** out, size_t count) {
         void* q = nullptr;
         hipError_t e = hipMalloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
@@ -623,12 +626,15 @@ extern "C" int svo_camera_to_world(int device, const float K[9], int n, const fl
     return SVO_OK;
 }
 
-extern "C" int svo_inverse_transform(const double R[9], const double t[3], double T[16]) {
+extern "C" int svo_inverse_transform(int device, const double R[9], const double t[3], double T[16]) {
     if (!R || !t || !T) return fail_arg("null argument");
-    for (int i = 0; i < 3; i++) {
-        for (int j = 0; j < 3; j++) T[4 * i + j] = R[3 * j + i];
-        T[4 * i + 3] = -(R[i] * t[0] + R[3 + i] * t[1] + R[6 + i] * t[2]);
-    }
-    T[12] = T[13] = T[14] = 0; T[15] = 1;
+    int rc = use_device(device); if (rc != SVO_OK) return rc;
+    DevTmp tmp; double* buf;
+    HIPCHK(tmp.get(&buf, 9 + 3 + 16));
+    HIPCHK(hipMemcpy(buf, R, sizeof(double) * 9, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(buf + 9, t, sizeof(double) * 3, hipMemcpyHostToDevice));
+    launch_inverse_transform(buf, buf + 9, buf + 12, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(T, buf + 12, sizeof(double) * 16, hipMemcpyDeviceToHost));
     return SVO_OK;
 }

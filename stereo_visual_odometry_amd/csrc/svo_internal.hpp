@@ -78,6 +78,7 @@ void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t s);      // gr
 void launch_compact(const DevBuffers& d, hipStream_t s);
 void launch_triangulate(const DevBuffers& d, hipStream_t s);
 void launch_pnp(const DevBuffers& d, hipStream_t s);
+void launch_inverse_transform(const double* R, const double* t, double* T, hipStream_t s);   // device pointers
 void launch_frame_end(const DevBuffers& d, int ring_slot, hipStream_t s);
 
 // stage helpers

@@ -643,6 +643,16 @@ static __device__ void lm_step(LmShared& sh) {
     for (int i = 0; i < 6; i++) sh.param[i] = sh.prev[i] - x[i];
 }
 
+
+// getInverseTransform (vo.cpp:246-258): [R t; 0 1]^-1 = [Rt, -Rt t; 0 1], row-major 4x4
+__device__ __forceinline__ void inverse_transform(const double* R, const double* t, double* T) {
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T[4 * i + j] = R[3 * j + i];
+        T[4 * i + 3] = -(R[i] * t[0] + R[3 + i] * t[1] + R[6 + i] * t[2]);
+    }
+    T[12] = T[13] = T[14] = 0; T[15] = 1;
+}
+
 __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
     const int seq = blockIdx.x;
     SeqState& s = d.st[seq];
@@ -757,14 +767,17 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
         rodrigues_to_vector(s.R, rv);                                                            // vo.cpp:125
         double angle = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);                     // vo.cpp:126
         if (tn > d.cfg.max_translation_norm || angle > d.cfg.max_rotation_norm) { s.fail_reason = 4; return; }   // vo.cpp:129-132
-        // getInverseTransform (vo.cpp:246-258): [R t; 0 1]^-1 = [Rt, -Rt t; 0 1]
-        for (int i = 0; i < 3; i++) {
-            for (int j = 0; j < 3; j++) s.last_T[4 * i + j] = s.R[3 * j + i];
-            s.last_T[4 * i + 3] = -(s.R[i] * s.t[0] + s.R[3 + i] * s.t[1] + s.R[6 + i] * s.t[2]);
-        }
-        s.last_T[12] = s.last_T[13] = s.last_T[14] = 0; s.last_T[15] = 1;
+        inverse_transform(s.R, s.t, s.last_T);                                                  // vo.cpp:133
         s.ok = 1;
     }
+}
+
+// ---- getInverseTransform (vo.cpp:246-258) as its own one-thread launch, for the stage API ----
+__global__ void k_inverse_transform(const double* __restrict__ R, const double* __restrict__ t, double* __restrict__ T) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) inverse_transform(R, t, T);
+}
+void launch_inverse_transform(const double* R, const double* t, double* T, hipStream_t st) {
+    hipLaunchKernelGGL(k_inverse_transform, dim3(1), dim3(64), 0, st, R, t, T);
 }
 
 #define PNP_FIRST_CHUNK 16

@@ -46,7 +46,8 @@ def test_oracle_and_product_config_structs_agree():
         assert getattr(a, f) == getattr(b, f), f
 
 
-def test_inverse_transform_host_entry_point():
+@pytest.mark.gpu
+def test_inverse_transform_entry_point():
     from stereo_visual_odometry_amd import api
     th = 0.3
     R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
@@ -63,6 +64,8 @@ def test_no_cpu_fallback():
         pytest.skip("a HIP device is present")
     with pytest.raises(_lib.SvoError):
         api.featureDetectionFast(np.zeros((32, 32), np.uint8), 20)
+    with pytest.raises(_lib.SvoError):                      # even the 12-flop closed form runs on the device
+        api.getInverseTransform(np.eye(3), np.zeros(3))
     with pytest.raises(_lib.SvoError):
         api.BatchVisualOdometry(64, 64, 1)
     with pytest.raises(_lib.SvoError):
