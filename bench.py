@@ -203,12 +203,25 @@ def main():
         traffic = None
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_lk_chain_pmc.json")))
-        if pmcs:
+        profiled = args.workload == "cfg2" and win == 21          # the committed counter passes are of this workload's kernel
+        if pmcs and profiled:
             try:
                 j = json.load(open(pmcs[-1]))
                 traffic = j["hbm_bytes_per_launch"] * Bc / float(j.get("sequences_per_launch", 32))
             except Exception:
                 traffic = None
+        # secondary (SURVEY.md 8d asks for the VALU view too, the kernel being instruction-bound): share of the GPU's VALU
+        # issue slots (1024 SIMDs, one wave64 instruction per 4 cycles, 2.4 GHz nominal) the LK instructions of this run take,
+        # from the committed SQ_INSTS_VALU pass
+        valu = None
+        sqs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_lk_chain_sq.json")))
+        if sqs and profiled:
+            try:
+                ipf = float(json.load(open(sqs[-1]))["valu_instructions_per_feature"])
+                valu = {"lk_valu_instructions_per_feature": ipf,
+                        "issue_slot_frac_at_2.4GHz": value / world * N * ipf / (1024 * 2.4e9 / 4)}
+            except Exception:
+                valu = None
         cpu = None
         if world == 1 and args.cpu_frames > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -255,7 +268,7 @@ def main():
                        "sequences_per_gpu": B, "contexts_per_gpu": C, "frames_in_flight": depth, "mean_features_into_lk": N,
                        "pose_ok_fraction": n_ok_all / float(world * B * args.steps)},
             "roofline": {"bound": "hbm", "kernel": "k_lk_chain<%d>" % win, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
+                         "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "valu_issue": valu,
                          "algorithmic_bytes_per_frame_pair": {"lk_chain": bytes_lk, "whole_frame": bytes_total},
                          "kernel_avg_ms": lk_avg_ms, "frame_avg_ms": float(np.mean(fr_ms)),
                          "whole_frame_frac": bytes_total * value / world / 1e9 / PEAK_HBM_GBS},

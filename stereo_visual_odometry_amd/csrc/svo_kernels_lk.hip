@@ -148,11 +148,31 @@ __device__ __forceinline__ void group_sums_to_float_narrow(const int (&partial)[
     for (int i = 0; i < N; i++) out[i] = (float)dpp_cross_rows<G>(u[i]);
 }
 
-__device__ __forceinline__ void lk_weights(float a, float b, int& iw00, int& iw01, int& iw10, int& iw11) {
-    iw00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << LK_WBITS));
-    iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << LK_WBITS));
-    iw10 = __float2int_rn((1.f - a) * b * (float)(1 << LK_WBITS));
-    iw11 = (1 << LK_WBITS) - iw00 - iw01 - iw10;
+// (upper half of a, lower half of b) as one packed pair
+__device__ __forceinline__ unsigned hi_lo16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040302u); }
+// low halves of two registers -> one packed pair (one v_perm_b32)
+__device__ __forceinline__ unsigned pack_lo16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
+
+// The four 14-bit bilinear weights of LKTrackerInvoker (lkpyramid.cpp: iw00 = cvRound((1-a)*(1-b)*(1 << W_BITS)), iw01,
+// iw10 likewise, iw11 = (1 << W_BITS) - iw00 - iw01 - iw10) as the two packed operands of the dot products:
+// w0 = (iw00, iw01), w1 = (iw10, iw11).  Bit-identical to the scalar recipe, in half the instructions:
+//  * the factor 2^14 is applied to (1-a, a) first — scaling by a power of two commutes with the rounding of the product;
+//  * round-half-even to integer is done by adding 1.5 * 2^23: the sum's low mantissa bits ARE the integer
+//    (0 <= x <= 2^14), so the 16-bit halves are taken straight from the float bits with v_perm;
+//  * packed f32 math (v_pk_mul_f32 / v_pk_add_f32) for the pairs.
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lk_weights(float a, float b, unsigned& w0, unsigned& w1) {
+    const float MAGIC = 12582912.f;                                   // 1.5 * 2^23, bits 0x4B400000
+    const float2v ab = {a, b};
+    const float2v om = 1.f - ab;                                      // (1-a, 1-b)
+    float2v A = {om.x, ab.x};
+    A *= (float)(1 << LK_WBITS);                                      // ((1-a) 2^14, a 2^14), exact
+    const float2v p = A * om.y + MAGIC;                               // iw00, iw01 as magic floats
+    const float q = A.x * ab.y + MAGIC;                               // iw10
+    const unsigned m00 = __float_as_uint(p.x), m01 = __float_as_uint(p.y), m10 = __float_as_uint(q);
+    const unsigned iw11 = ((1u << LK_WBITS) + 3u * 0x4B400000u) - (m00 + m01 + m10);
+    w0 = pack_lo16((int)m00, (int)m01);
+    w1 = pack_lo16((int)m10, (int)iw11);
 }
 
 struct LkCrit { int max_count; double eps2; double min_eig; };
@@ -171,10 +191,6 @@ __device__ __forceinline__ int dot2_keep(unsigned a, unsigned b, int acc) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), acc, true);
 }
 __device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
-// (upper half of a, lower half of b) as one packed pair
-__device__ __forceinline__ unsigned hi_lo16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040302u); }
-// low halves of two registers -> one packed pair (one v_perm_b32)
-__device__ __forceinline__ unsigned pack_lo16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
 
 // N bytes at p (any alignment) -> N-1 packed pairs: pair[x] = byte[x] | byte[x+1] << 16 (one v_perm_b32 each)
 template <int N>
@@ -222,9 +238,8 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             if (level == 0) status = 0;
             continue;
         }
-        int iw00, iw01, iw10, iw11;
-        lk_weights(ppx - (float)ipx, ppy - (float)ipy, iw00, iw01, iw10, iw11);
-        unsigned w0 = pack16(iw00, iw01), w1 = pack16(iw10, iw11);
+        unsigned w0, w1;
+        lk_weights(ppx - (float)ipx, ppy - (float)ipy, w0, w1);
         // ---- template: per segment 4 rows x NS source bytes, origin (ipx-1+xs, ipy-1+row); REFLECT_101 = the pyramid border.
         // Everything is kept as packed 16-bit PAIRS (value[c], value[c+1]) — the operand layout of v_dot2c_i32_i16 —
         // and the Scharr derivatives are computed with packed 16-bit math directly on those pairs:
@@ -368,8 +383,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         };
         // one Newton step against the window loaded at integer origin (fx0, fy0); returns true when the track is finished
         auto newton_step = [&](float fx0, float fy0) __attribute__((always_inline)) -> bool {
-            lk_weights(nx - fx0, ny - fy0, iw00, iw01, iw10, iw11);
-            w0 = pack16(iw00, iw01); w1 = pack16(iw10, iw11);
+            lk_weights(nx - fx0, ny - fy0, w0, w1);
             int pb1 = 0, pb2 = 0;
 #pragma unroll
             for (int k = 0; k < SPL; k++) {
