@@ -359,6 +359,18 @@ def test_batch_equals_single(api):
 
 
 # ---------------------------------------------------------------- the other BASELINE.json configs as parity cases
+def test_max_features_preset_keeps_the_first_n_in_bucket_order(api):
+    """The build preset of SURVEY.md 8d cfg2 (not in the reference): only the first max_features of the bucketed set enter
+    circularMatching, the rest are dropped from the feature set; oracle and product must agree on every frame."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=480, height=200, cx=240.0, cy=100.0)
+    seq = syn.StereoSequence(cal=cal, n_frames=4, seed=31, step=0.4)
+    free = run_both(api, seq, dict(win_w=10, win_h=10, max_translation_norm=2.0), 2)
+    assert free[1][2]["n_into_lk"] > 250
+    res = run_both(api, seq, dict(win_w=10, win_h=10, max_translation_norm=2.0, max_features=200), 4)
+    assert all(r[2]["n_into_lk"] == 200 for r in res[1:]) and all(r[0] for r in res[1:])
+
+
 def test_cfg3_four_levels_1000_ransac_iterations(api):
     """configs[2]: KITTI-00 shaped, maxLevel 4 (5 levels), 1000 RANSAC-PnP iterations, denser features."""
     from stereo_visual_odometry_amd import synthetic as syn
