@@ -371,6 +371,27 @@ def test_max_features_preset_keeps_the_first_n_in_bucket_order(api):
     assert all(r[2]["n_into_lk"] == 200 for r in res[1:]) and all(r[0] for r in res[1:])
 
 
+@pytest.mark.parametrize("over", [
+    dict(win_w=15, win_h=15, max_level=2, buckets_along_height=40, buckets_along_width=64, bucket_start_row=2, fast_threshold=30,
+         age_threshold=3, features_threshold=10, pre_matching_feature_threshold=50, ransac_reprojection_error=2.0,
+         ransac_confidence=0.9, ransac_iterations=40, lk_max_count=10, lk_epsilon=1e-2,
+         circular_matching_success_threshold=0.3, optical_flow_min_eig_threshold=1e-2, max_translation_norm=2.0),
+    dict(win_w=7, win_h=7, max_level=4, buckets_along_height=23, buckets_along_width=31, bucket_start_row=0, fast_threshold=12,
+         age_threshold=2, features_threshold=25, pre_matching_feature_threshold=2000, ransac_reprojection_error=0.7,
+         ransac_confidence=0.999, ransac_iterations=300, lk_max_count=100, lk_epsilon=0.0,
+         circular_matching_success_threshold=0.05, optical_flow_min_eig_threshold=1e-4, max_translation_norm=0.45,
+         max_rotation_norm=0.004),
+], ids=["coarse-grid-loose", "fine-grid-strict"])
+def test_every_config_knob_away_from_its_default(api, over):
+    """All run-time constants of vo.h:53-127 / :251-252 moved off the reference values at once (the second set forces the
+    second FAST pass every frame, a tight RANSAC threshold and motion gates that trip on some frames)."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=512, height=224, cx=256.0, cy=112.0)
+    seq = syn.StereoSequence(cal=cal, n_frames=7, seed=77, step=0.4, yaw_amp_deg=0.3)
+    res = run_both(api, seq, over, 7)
+    assert any(r[0] for r in res[1:])                            # not vacuous: poses were produced
+
+
 def test_cfg3_four_levels_1000_ransac_iterations(api):
     """configs[2]: KITTI-00 shaped, maxLevel 4 (5 levels), 1000 RANSAC-PnP iterations, denser features."""
     from stereo_visual_odometry_amd import synthetic as syn
