@@ -169,6 +169,10 @@ def main():
             col += 1
 
     run(0, args.warmup + 1, False)                           # frame 0 only primes the pipeline (vo.cpp:47-56), then W warm-up steps
+    if world > 1:
+        # warm-up of the exchange as well: the first gather / all-reduce set up RCCL's point-to-point channels
+        sharding.gather_pose_streams(torch.zeros(poses.shape, dtype=torch.float64, device=comm_dev), dst=0)
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=comm_dev), op=dist.ReduceOp.MAX)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
