@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--seqs", type=int, default=128, help="independent stereo sequences batched per GPU")
+    ap.add_argument("--seqs", type=int, default=256, help="independent stereo sequences batched per GPU")
     ap.add_argument("--depth", type=int, default=4, help="frames kept in flight per context (<= 8)")
     ap.add_argument("--contexts", type=int, default=2, help="sequence groups per GPU, each on its own HIP stream (their kernels overlap)")
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic sequences rendered per rank")
