@@ -98,13 +98,25 @@ __global__ __launch_bounds__(256) void k_pyrdown(DevBuffers d, int level) {
     const uint8_t* src = base + ls.off;
     uint8_t* dst = base + ld.off;
     constexpr int SW = 2 * PD_TW + 3, SH = 2 * PD_TH + 3;        // 67 x 19 source tile
-    __shared__ uint8_t tile[SH][SW + 1];
+    __shared__ __attribute__((aligned(4))) uint8_t tile[SH][SW + 1];
     __shared__ unsigned short hrow[SH][PD_TW];                   // horizontal pass result (<= 16*255)
     const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
     const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
-    for (int i = threadIdx.x; i < SW * SH; i += 256) {
-        int ty = i / SW, tx = i - ty * SW;
-        tile[ty][tx] = src[(size_t)reflect101(sy0 + ty, ls.h) * ls.w + reflect101(sx0 + tx, ls.w)];
+    if (sx0 >= 0 && sy0 >= 0 && sx0 + SW + 1 <= ls.w && sy0 + SH <= ls.h) {
+        // interior tile (almost all of them): 17 unaligned dword loads per source row, no border arithmetic
+        static_assert((SW + 1) % 4 == 0, "tile rows are whole dwords");
+        struct __attribute__((packed, aligned(1))) UD { unsigned v; };
+        constexpr int DPR = (SW + 1) / 4;
+        for (int i = threadIdx.x; i < DPR * SH; i += 256) {
+            int ty = i / DPR, c = i - ty * DPR;
+            const unsigned v = reinterpret_cast<const UD*>(src + (size_t)(sy0 + ty) * ls.w + sx0 + 4 * c)->v;
+            *reinterpret_cast<unsigned*>(&tile[ty][4 * c]) = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < SW * SH; i += 256) {
+            int ty = i / SW, tx = i - ty * SW;
+            tile[ty][tx] = src[(size_t)reflect101(sy0 + ty, ls.h) * ls.w + reflect101(sx0 + tx, ls.w)];
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SH * PD_TW; i += 256) {
@@ -196,8 +208,10 @@ __device__ __forceinline__ unsigned long long make_bucket_key(int score, unsigne
 template <bool TO_BUCKETS>
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* img_single, int w_single, int h_single, uint8_t* score_out,
                                               DevBuffers d, int pass, int threshold) {
-    __shared__ uint8_t pix[FT_PH][FT_PW + 4];
+    __shared__ __attribute__((aligned(4))) uint8_t pix[FT_PH][FT_PW + 4];
     __shared__ uint8_t sc[FT_SH][FT_SW + 2];
+    __shared__ unsigned short cand[FT_SH * FT_SW];               // screened pixels of the tile (order is irrelevant)
+    __shared__ int ncand;
     const int seq = blockIdx.z;
     int W, H; const uint8_t* img;
     if (TO_BUCKETS) {
@@ -209,18 +223,46 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* img_single, int w_s
     if (threshold < 0) threshold = 0;
     if (threshold > 255) threshold = 255;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
-    for (int i = threadIdx.x; i < FT_PH * FT_PW; i += 256) {
-        int py = i / FT_PW, px = i - py * FT_PW;
-        int gx = x0 - 4 + px, gy = y0 - 4 + py;
-        pix[py][px] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(size_t)gy * W + gx] : (uint8_t)0;
+    if (x0 >= 4 && y0 >= 4 && x0 - 4 + FT_PW <= W && y0 - 4 + FT_PH <= H) {
+        // interior tile: 18 unaligned dword loads per row instead of 72 guarded byte loads
+        static_assert(FT_PW % 4 == 0, "tile rows are whole dwords");
+        struct __attribute__((packed, aligned(1))) UD { unsigned v; };
+        constexpr int DPR = FT_PW / 4;
+        for (int i = threadIdx.x; i < DPR * FT_PH; i += 256) {
+            int py = i / DPR, c = i - py * DPR;
+            const unsigned v = reinterpret_cast<const UD*>(img + (size_t)(y0 - 4 + py) * W + (x0 - 4) + 4 * c)->v;
+            *reinterpret_cast<unsigned*>(&pix[py][4 * c]) = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < FT_PH * FT_PW; i += 256) {
+            int py = i / FT_PW, px = i - py * FT_PW;
+            int gx = x0 - 4 + px, gy = y0 - 4 + py;
+            pix[py][px] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(size_t)gy * W + gx] : (uint8_t)0;
+        }
     }
+    if (threadIdx.x == 0) ncand = 0;
     __syncthreads();
+    // Screening: a 9-arc of the 16-pixel circle contains at least one pixel of every antipodal pair, so a corner needs a
+    // darker (or a brighter) member in each of the pairs (0,8) and (4,12).  Typically ~7 % of the pixels pass (th = 20);
+    // only those are queued for the full 16-pixel test, which then runs on densely packed waves.
     for (int i = threadIdx.x; i < FT_SH * FT_SW; i += 256) {
         int sy = i / FT_SW, sx = i - sy * FT_SW;
         int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
-        int s = 0;
-        if (gx >= 3 && gx < W - 3 && gy >= 3 && gy < H - 3) s = fast_score(pix, sy + 3, sx + 3, threshold);
-        sc[sy][sx] = (uint8_t)s;
+        sc[sy][sx] = 0;
+        if (gx >= 3 && gx < W - 3 && gy >= 3 && gy < H - 3) {
+            const int py = sy + 3, px = sx + 3;
+            const int v = pix[py][px], lo = v - threshold, hi = v + threshold;
+            const int a = pix[py + 3][px], b = pix[py - 3][px], c = pix[py][px + 3], e = pix[py][px - 3];   // circle 0, 8, 4, 12
+            const bool dark = (a < lo || b < lo) && (c < lo || e < lo);
+            const bool bright = (a > hi || b > hi) && (c > hi || e > hi);
+            if (dark || bright) cand[atomicAdd(&ncand, 1)] = (unsigned short)i;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ncand; k += 256) {
+        const int i = cand[k];
+        int sy = i / FT_SW, sx = i - sy * FT_SW;
+        sc[sy][sx] = (uint8_t)fast_score(pix, sy + 3, sx + 3, threshold);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < FT_W * FT_H; i += 256) {
