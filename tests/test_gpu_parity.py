@@ -474,3 +474,42 @@ def test_soak_sequences_stay_bit_exact(api, seed, step, yaw, win):
             assert np.abs(T_o[:3, 3] - T[i][:3, 3]).max() < POSE_TOL_T and rot_angle(T_o[:3, :3], T[i][:3, :3]) < POSE_TOL_R, (k, i)
             n_ok += int(ok_o)
     assert n_ok > 40                                    # the sequences really produce poses most of the time
+
+
+class _Frames:
+    """A rendered sequence with its images post-processed (contrast, noise, black bars) — same interface run_both uses."""
+    def __init__(self, seq, left, right):
+        self.cal, self.left, self.right = seq.cal, left, right
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_fuzz_scenes_and_configs(api, case):
+    """Seeded random scenes x image degradations x configurations: high contrast (the wide LK reductions), low contrast
+    (minimum-eigenvalue rejections), noise, black bars (windows over flat areas and borders), every window / level count,
+    loose and strict thresholds.  Everything a frame produces must match the oracle on every frame."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    rng = np.random.default_rng(9000 + case)
+    w, h = int(rng.choice([320, 352, 417])), int(rng.choice([160, 176, 203]))
+    cal = dict(syn.KITTI00, width=w, height=h, cx=w / 2.0, cy=h / 2.0)
+    seq = syn.StereoSequence(cal=cal, n_frames=4, seed=500 + case, step=float(rng.uniform(0.1, 0.7)),
+                             yaw_amp_deg=float(rng.uniform(0.0, 1.2)), cell_px=float(rng.uniform(9.0, 22.0)))
+    gain, bias, sigma = float(rng.choice([0.35, 1.0, 1.0, 2.5])), float(rng.uniform(-20, 20)), float(rng.choice([0.0, 0.0, 2.0, 6.0]))
+    bar = int(rng.choice([0, 0, 12, 30]))
+
+    def degrade(img, k, cam):
+        f = (img.astype(np.float64) - 128.0) * gain + 128.0 + bias
+        if sigma > 0:
+            f = f + np.random.default_rng(77 * case + 2 * k + cam).normal(0.0, sigma, img.shape)
+        out = np.clip(np.rint(f), 0, 255).astype(np.uint8)
+        if bar:
+            out[:, :bar] = 0; out[-bar // 2:, :] = 255
+        return out
+
+    fr = _Frames(seq, [degrade(seq.left[k], k, 0) for k in range(4)], [degrade(seq.right[k], k, 1) for k in range(4)])
+    win = int(rng.choice([7, 10, 15, 21, 31]))
+    over = dict(win_w=win, win_h=win, max_level=int(rng.integers(1, 5)), fast_threshold=int(rng.choice([8, 20, 35])),
+                ransac_iterations=int(rng.choice([20, 100, 250])), ransac_reprojection_error=float(rng.choice([1.0, 8.0])),
+                optical_flow_min_eig_threshold=float(rng.choice([1e-4, 1e-3, 3e-2])),
+                circular_matching_success_threshold=float(rng.choice([0.05, 0.15, 0.6])),
+                lk_max_count=int(rng.choice([5, 30])), max_translation_norm=2.0)
+    run_both(api, fr, over, 4)
