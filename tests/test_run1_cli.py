@@ -115,3 +115,16 @@ def test_cli_reads_both_calibration_key_styles(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append(evaluate.read_result_csv(res))
     assert np.array_equal(outs[0], outs[1]) and outs[0].shape == (3, 5)
+
+
+def test_report_trajectory_tool(tmp_path):
+    """tools/report_trajectory.py (counterpart of visualize_data.py): figures and plot from the recorded run1 rows."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import report_trajectory
+    d = np.load(FIX)
+    csv = tmp_path / "result.csv"
+    np.savetxt(csv, d["result_csv"], delimiter=",", header="x,y,z,gtx,gty", comments="")
+    png = tmp_path / "track.png"
+    e = report_trajectory.main([str(csv), "--ref", str(csv), "--plot", str(png)])
+    assert e == evaluate.endpoint_error(d["result_csv"]) and png.stat().st_size > 1000
