@@ -124,6 +124,17 @@ void orc_lk_track(const orc_pyramid* prev, const orc_pyramid* next, int n, const
                   float* next_pts, uint8_t* status, int win_w, int win_h, int max_level,
                   int max_count, double epsilon, double min_eig_threshold);
 
+/* Multi-channel form (cv::calcOpticalFlowPyrLK with cn = image channels: the window sums run over all channels of every
+ * pixel, lkpyramid.cpp LKTrackerInvoker `x < winSize.width*cn`).  prev / next: cn single-channel pyramids, one per colour
+ * plane — plane k of a pyramid built from an interleaved image equals channel k of OpenCV's cn-channel pyramid, because
+ * pyrDown, the Scharr derivative and the bilinear patch sampling all act per channel.  cn = 1 is orc_lk_track. */
+#define ORC_MAX_CN 3
+void orc_lk_track_cn(int cn, const orc_pyramid* const* prev, const orc_pyramid* const* next, int n, const float* prev_pts,
+                     float* next_pts, uint8_t* status, int win_w, int win_h, int max_level,
+                     int max_count, double epsilon, double min_eig_threshold);
+/* channel k of an interleaved cn-channel image -> contiguous w x h plane */
+void orc_extract_plane(const uint8_t* img, int w, int h, int stride, int cn, int k, uint8_t* plane);
+
 /* ---- helpers (vo.cpp:144-168, 265-280) ---- */
 void orc_find_close_points(int n, const float* p1, const float* p2, float threshold, uint8_t* ok);
 
@@ -131,6 +142,10 @@ void orc_find_close_points(int n, const float* p1, const float* p2, float thresh
 void orc_circular_match(const orc_pyramid* l0, const orc_pyramid* r0, const orc_pyramid* l1, const orc_pyramid* r1,
                         int n, const float* pl0, float* pl1, float* pr1, float* pr0, float* pl0_circle,
                         uint8_t* ok, const orc_config* cfg);
+
+void orc_circular_match_cn(int cn, const orc_pyramid* const* l0, const orc_pyramid* const* r0, const orc_pyramid* const* l1,
+                           const orc_pyramid* const* r1, int n, const float* pl0, float* pl1, float* pr1, float* pr0,
+                           float* pl0_circle, uint8_t* ok, const orc_config* cfg);
 
 /* ---- triangulation (cv::triangulatePoints + convertPointsFromHomogeneous, vo.cpp:89-94) ---- */
 void orc_triangulate(const float Pl[12], const float Pr[12], int n, const float* pts_l, const float* pts_r,
@@ -184,6 +199,12 @@ void    orc_vo_set_projection(orc_vo* vo, const float Pl[12], const float Pr[12]
 /* returns 1 if ok (pose produced), 0 otherwise; T_out always gets the "second" of the pair (vo.cpp:43-44,136). */
 int     orc_vo_stereo_callback(orc_vo* vo, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
                                double T_out[16], orc_frame_stats* stats);
+/* The same callback on cn-channel interleaved images (cn = 1 or 3; stride in bytes).  cn = 3 restates what the reference CLI
+ * really runs: readImages returns the BGR Mats (main.cpp:38-46), so cv::FAST — which has no channel
+ * check — walks the first `w` BYTES of every row of the interleaved image (byte column = keypoint x), while the pyramids and LK
+ * are genuinely 3-channel.  Pinned by the reference's own recording: run1/result.csv (tests/test_run1_color.py). */
+int     orc_vo_stereo_callback_cn(orc_vo* vo, const uint8_t* left, const uint8_t* right, int w, int h, int stride, int cn,
+                                  double T_out[16], orc_frame_stats* stats);
 /* introspection for parity tests */
 int     orc_vo_num_features(const orc_vo* vo);
 void    orc_vo_get_features(const orc_vo* vo, float* xy, int* ages, int* strengths);

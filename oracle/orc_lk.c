@@ -132,13 +132,14 @@ static inline int cv_round_f(float v) { return (int)lrintf(v); }     /* round-ha
 static inline int cv_floor_f(float v) { return (int)floorf(v); }
 
 /* One pyramid level of LKTrackerInvoker for all points. */
-static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int max_level, int n,
+static void lk_level(int cn, const orc_pyramid* const* Apl, const orc_pyramid* const* Bpl, int level, int max_level, int n,
                      const float* prev_pts, float* next_pts, uint8_t* status,
                      int ww, int wh, int max_count, double epsilon, double min_eig_threshold) {
     const float half_x = (ww - 1) * 0.5f, half_y = (wh - 1) * 0.5f;
-    const uint8_t* I = A->img[level]; const int stepI = A->img_stride[level];
-    const int16_t* dI = A->deriv[level]; const int dstep = A->deriv_stride[level];
-    const uint8_t* J = B->img[level]; const int stepJ = B->img_stride[level];
+    const orc_pyramid* A = Apl[0]; const orc_pyramid* B = Bpl[0];          /* all planes share the geometry */
+    const int stepI = A->img_stride[level];
+    const int dstep = A->deriv_stride[level];
+    const int stepJ = B->img_stride[level];
     const int colsI = A->w[level], rowsI = A->h[level], colsJ = B->w[level], rowsJ = B->h[level];
     const float FLT_SCALE = 1.f / (1 << 20);
     const float scale = (float)(1. / (1 << level));
@@ -147,9 +148,9 @@ static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int 
     /* points are independent (cv::parallel_for_ over points in calcOpticalFlowPyrLK): one patch buffer per thread */
 #pragma omp parallel
     {
-    int16_t* Iw = (int16_t*)malloc(sizeof(int16_t) * (size_t)ww * wh * 3);
-    int16_t* dIw = Iw + (size_t)ww * wh;
-    int x, y, j;
+    int16_t* Iw = (int16_t*)malloc(sizeof(int16_t) * (size_t)ww * wh * 3 * cn);
+    int16_t* dIw = Iw + (size_t)ww * wh * cn;
+    int x, y, j, pc;
 #pragma omp for schedule(dynamic, 16)
     for (i = 0; i < n; i++) {
         float ppx = prev_pts[2 * i] * scale, ppy = prev_pts[2 * i + 1] * scale;
@@ -172,11 +173,12 @@ static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int 
         int iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         int64_t iA11 = 0, iA12 = 0, iA22 = 0;
+        for (pc = 0; pc < cn; pc++)                       /* window sums run over every channel (lkpyramid.cpp: x < winSize.width*cn) */
         for (y = 0; y < wh; y++) {
-            const uint8_t* src = I + (ptrdiff_t)(y + ipy) * stepI + ipx;
-            const int16_t* ds = dI + (ptrdiff_t)(y + ipy) * dstep + ipx * 2;
-            int16_t* Ip = Iw + (size_t)y * ww;
-            int16_t* dp = dIw + (size_t)y * ww * 2;
+            const uint8_t* src = Apl[pc]->img[level] + (ptrdiff_t)(y + ipy) * stepI + ipx;
+            const int16_t* ds = Apl[pc]->deriv[level] + (ptrdiff_t)(y + ipy) * dstep + ipx * 2;
+            int16_t* Ip = Iw + (size_t)(pc * wh + y) * ww;
+            int16_t* dp = dIw + (size_t)(pc * wh + y) * ww * 2;
             for (x = 0; x < ww; x++, ds += 2, dp += 2) {
                 int ival = DESCALE(src[x] * iw00 + src[x + 1] * iw01 + src[x + stepI] * iw10 + src[x + stepI + 1] * iw11, W_BITS - 5);
                 int ixval = DESCALE(ds[0] * iw00 + ds[2] * iw01 + ds[dstep] * iw10 + ds[dstep + 2] * iw11, W_BITS);
@@ -212,10 +214,11 @@ static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int 
             iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
             int64_t ib1 = 0, ib2 = 0;
+            for (pc = 0; pc < cn; pc++)
             for (y = 0; y < wh; y++) {
-                const uint8_t* Jp = J + (ptrdiff_t)(y + iny) * stepJ + inx;
-                const int16_t* Ip = Iw + (size_t)y * ww;
-                const int16_t* dp = dIw + (size_t)y * ww * 2;
+                const uint8_t* Jp = Bpl[pc]->img[level] + (ptrdiff_t)(y + iny) * stepJ + inx;
+                const int16_t* Ip = Iw + (size_t)(pc * wh + y) * ww;
+                const int16_t* dp = dIw + (size_t)(pc * wh + y) * ww * 2;
                 for (x = 0; x < ww; x++, dp += 2) {
                     int diff = DESCALE(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stepJ] * iw10 + Jp[x + stepJ + 1] * iw11, W_BITS - 5) - Ip[x];
                     ib1 += (int64_t)(diff * dp[0]); ib2 += (int64_t)(diff * dp[1]);
@@ -243,10 +246,11 @@ static void lk_level(const orc_pyramid* A, const orc_pyramid* B, int level, int 
     }
 }
 
-void orc_lk_track(const orc_pyramid* prev, const orc_pyramid* next, int n, const float* prev_pts,
+void orc_lk_track_cn(int cn, const orc_pyramid* const* prevs, const orc_pyramid* const* nexts, int n, const float* prev_pts,
                   float* next_pts, uint8_t* status, int win_w, int win_h, int max_level,
                   int max_count, double epsilon, double min_eig_threshold) {
     int level, i;
+    const orc_pyramid* prev = prevs[0]; const orc_pyramid* next = nexts[0];
     if (max_level > prev->nlevels - 1) max_level = prev->nlevels - 1;
     if (max_level > next->nlevels - 1) max_level = next->nlevels - 1;
     /* TermCriteria normalisation (lkpyramid.cpp) */
@@ -257,20 +261,41 @@ void orc_lk_track(const orc_pyramid* prev, const orc_pyramid* next, int n, const
     epsilon *= epsilon;
     for (i = 0; i < n; i++) status[i] = 1;
     for (level = max_level; level >= 0; level--)
-        lk_level(prev, next, level, max_level, n, prev_pts, next_pts, status, win_w, win_h, max_count, epsilon, min_eig_threshold);
+        lk_level(cn, prevs, nexts, level, max_level, n, prev_pts, next_pts, status, win_w, win_h, max_count, epsilon, min_eig_threshold);
 }
 
 /* vo.cpp:169-240 without the compaction (the mask is returned) */
-void orc_circular_match(const orc_pyramid* l0, const orc_pyramid* r0, const orc_pyramid* l1, const orc_pyramid* r1,
+void orc_lk_track(const orc_pyramid* prev, const orc_pyramid* next, int n, const float* prev_pts,
+                  float* next_pts, uint8_t* status, int win_w, int win_h, int max_level,
+                  int max_count, double epsilon, double min_eig_threshold) {
+    orc_lk_track_cn(1, &prev, &next, n, prev_pts, next_pts, status, win_w, win_h, max_level, max_count, epsilon, min_eig_threshold);
+}
+
+void orc_extract_plane(const uint8_t* img, int w, int h, int stride, int cn, int k, uint8_t* plane) {
+    int x, y;
+    for (y = 0; y < h; y++) {
+        const uint8_t* r = img + (size_t)y * stride + k;
+        uint8_t* d = plane + (size_t)y * w;
+        for (x = 0; x < w; x++) d[x] = r[(size_t)x * cn];
+    }
+}
+
+void orc_circular_match_cn(int cn, const orc_pyramid* const* l0, const orc_pyramid* const* r0, const orc_pyramid* const* l1, const orc_pyramid* const* r1,
                         int n, const float* pl0, float* pl1, float* pr1, float* pr0, float* pl0_circle,
                         uint8_t* ok, const orc_config* cfg) {
     uint8_t* st = (uint8_t*)malloc((size_t)n * 4 + 4);
     int i;
-    orc_lk_track(l0, l1, n, pl0, pl1, st, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold);          /* :203 */
-    orc_lk_track(l1, r1, n, pl1, pr1, st + n, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold);      /* :206 */
-    orc_lk_track(r1, r0, n, pr1, pr0, st + 2 * n, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold);  /* :209 */
-    orc_lk_track(r0, l0, n, pr0, pl0_circle, st + 3 * n, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold); /* :213 */
+    orc_lk_track_cn(cn, l0, l1, n, pl0, pl1, st, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold);          /* :203 */
+    orc_lk_track_cn(cn, l1, r1, n, pl1, pr1, st + n, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold);      /* :206 */
+    orc_lk_track_cn(cn, r1, r0, n, pr1, pr0, st + 2 * n, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold);  /* :209 */
+    orc_lk_track_cn(cn, r0, l0, n, pr0, pl0_circle, st + 3 * n, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold); /* :213 */
     orc_find_close_points(n, pl0, pl0_circle, (float)cfg->circular_matching_success_threshold, ok);   /* :217-219 (float32 threshold parameter) */
     for (i = 0; i < n; i++) ok[i] = (uint8_t)(st[i] && st[n + i] && st[2 * n + i] && st[3 * n + i] && ok[i]);  /* :227-230 */
     free(st);
+}
+
+void orc_circular_match(const orc_pyramid* l0, const orc_pyramid* r0, const orc_pyramid* l1, const orc_pyramid* r1,
+                        int n, const float* pl0, float* pl1, float* pr1, float* pr0, float* pl0_circle,
+                        uint8_t* ok, const orc_config* cfg) {
+    orc_circular_match_cn(1, &l0, &r0, &l1, &r1, n, pl0, pl1, pr1, pr0, pl0_circle, ok, cfg);
 }

@@ -36,8 +36,9 @@ struct orc_vo {
     orc_config cfg;
     int frame_id;
     int w, h;
-    uint8_t *imgL0, *imgR0;          /* imageLeftT0_, imageRightT0_ (vo.h:239) */
-    orc_pyramid pyrL0, pyrR0;        /* lastLeftPyramid, lastRightPyramid (vo.h:257-258) */
+    int cn;                          /* channels of the images being fed (1, or 3 = the reference CLI's BGR input) */
+    uint8_t *imgL0, *imgR0;          /* imageLeftT0_, imageRightT0_ (vo.h:239), interleaved, row stride w * cn */
+    orc_pyramid pyrL0[ORC_MAX_CN], pyrR0[ORC_MAX_CN];   /* lastLeftPyramid, lastRightPyramid (vo.h:257-258), one per colour plane */
     int have_pyr;
     /* currentVOFeatures (vo.h:245) */
     int nf, capf; float* fxy; int* fage; int* fstr;
@@ -73,7 +74,7 @@ static void free_tracks(orc_vo* vo) {
 void orc_vo_destroy(orc_vo* vo) {
     if (!vo) return;
     free(vo->imgL0); free(vo->imgR0);
-    if (vo->have_pyr) { orc_pyramid_free(&vo->pyrL0); orc_pyramid_free(&vo->pyrR0); }
+    if (vo->have_pyr) { int k; for (k = 0; k < vo->cn; k++) { orc_pyramid_free(&vo->pyrL0[k]); orc_pyramid_free(&vo->pyrR0[k]); } }
     free(vo->fxy); free(vo->fage); free(vo->fstr);
     free_tracks(vo);
     free(vo);
@@ -105,12 +106,13 @@ static void compact_features(orc_vo* vo, const uint8_t* ok, int n_ok_len) {
 }
 
 /* feature_set.cpp:75-89 */
+/* img: the interleaved image; cv::FAST has no channel check and scans the first w BYTES of every row (Appendix B-1) */
 static void append_features_from_image(orc_vo* vo, const uint8_t* img, int w, int h, int fast_threshold) {
     const orc_config* c = &vo->cfg;
     int cap = w * h / 4 + 16, i;
     float* xy = (float*)malloc(sizeof(float) * 2 * (size_t)cap);
     float* resp = (float*)malloc(sizeof(float) * (size_t)cap);
-    int n = orc_fast_detect(img, w, h, w, fast_threshold, 1, cap, xy, resp);
+    int n = orc_fast_detect(img, w, h, w * vo->cn, fast_threshold, 1, cap, xy, resp);
     if (n > cap) n = cap;
     ensure_cap(vo, vo->nf + n);
     for (i = 0; i < n; i++) {
@@ -124,22 +126,42 @@ static void append_features_from_image(orc_vo* vo, const uint8_t* img, int w, in
     free(xy); free(resp);
 }
 
+/* cn single-channel pyramids of an interleaved image (buildOpticalFlowPyramid on a cn-channel Mat works per channel) */
+static void build_plane_pyramids(const uint8_t* img, int w, int h, int cn, const orc_config* c, orc_pyramid* out) {
+    int k;
+    if (cn == 1) { orc_build_pyramid(img, w, h, w, c->win_w, c->win_h, c->max_level, &out[0]); return; }
+    uint8_t* plane = (uint8_t*)malloc((size_t)w * h);
+    for (k = 0; k < cn; k++) {
+        orc_extract_plane(img, w, h, w * cn, cn, k, plane);
+        orc_build_pyramid(plane, w, h, w, c->win_w, c->win_h, c->max_level, &out[k]);
+    }
+    free(plane);
+}
+
 int orc_vo_stereo_callback(orc_vo* vo, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
                            double T_out[16], orc_frame_stats* st) {
+    return orc_vo_stereo_callback_cn(vo, left, right, w, h, stride, 1, T_out, st);
+}
+
+int orc_vo_stereo_callback_cn(orc_vo* vo, const uint8_t* left, const uint8_t* right, int w, int h, int stride, int cn,
+                              double T_out[16], orc_frame_stats* st) {
     const orc_config* c = &vo->cfg;
-    orc_frame_stats local; int i, y;
+    orc_frame_stats local; int i, y, k;
+    if (cn != 1 && cn != ORC_MAX_CN) return -1;
+    if (vo->frame_id > 0 && cn != vo->cn) return -1;
     if (!st) st = &local;
     memset(st, 0, sizeof(*st));
     memcpy(T_out, vo->last_transform, sizeof(double) * 16);          /* fail_result (vo.cpp:43-44) */
     /* contiguous copies of the inputs (T1) */
-    uint8_t* L1 = (uint8_t*)malloc((size_t)w * h);
-    uint8_t* R1 = (uint8_t*)malloc((size_t)w * h);
-    for (y = 0; y < h; y++) { memcpy(L1 + (size_t)y * w, left + (size_t)y * stride, (size_t)w); memcpy(R1 + (size_t)y * w, right + (size_t)y * stride, (size_t)w); }
+    const size_t rowb = (size_t)w * cn;
+    uint8_t* L1 = (uint8_t*)malloc(rowb * h);
+    uint8_t* R1 = (uint8_t*)malloc(rowb * h);
+    for (y = 0; y < h; y++) { memcpy(L1 + (size_t)y * rowb, left + (size_t)y * stride, rowb); memcpy(R1 + (size_t)y * rowb, right + (size_t)y * stride, rowb); }
 
     if (vo->frame_id == 0) {                                          /* vo.cpp:47-56 */
-        vo->w = w; vo->h = h; vo->imgL0 = L1; vo->imgR0 = R1;
-        orc_build_pyramid(L1, w, h, w, c->win_w, c->win_h, c->max_level, &vo->pyrL0);
-        orc_build_pyramid(R1, w, h, w, c->win_w, c->win_h, c->max_level, &vo->pyrR0);
+        vo->w = w; vo->h = h; vo->cn = cn; vo->imgL0 = L1; vo->imgR0 = R1;
+        build_plane_pyramids(L1, w, h, cn, c, vo->pyrL0);
+        build_plane_pyramids(R1, w, h, cn, c, vo->pyrR0);
         vo->have_pyr = 1; vo->frame_id++;
         st->fail_reason = 1; st->n_features_out = vo->nf;
         return 0;
@@ -166,12 +188,16 @@ int orc_vo_stereo_callback(orc_vo* vo, const uint8_t* left, const uint8_t* right
     memcpy(pl0, vo->fxy, sizeof(float) * 2 * (size_t)n);                             /* :338 */
     int nt = 0;
     if (n > 0) {                                                                     /* circularMatching :179-181 */
-        orc_pyramid pl1p, pr1p;
-        orc_build_pyramid(L1, w, h, w, c->win_w, c->win_h, c->max_level, &pl1p);     /* :200 */
-        orc_build_pyramid(R1, w, h, w, c->win_w, c->win_h, c->max_level, &pr1p);     /* :201 */
-        orc_circular_match(&vo->pyrL0, &vo->pyrR0, &pl1p, &pr1p, n, pl0, pl1, pr1, pr0, plc, ok, c);   /* :203-230 */
-        orc_pyramid_free(&vo->pyrL0); orc_pyramid_free(&vo->pyrR0);
-        vo->pyrL0 = pl1p; vo->pyrR0 = pr1p;                                          /* :231-232 */
+        orc_pyramid pl1p[ORC_MAX_CN], pr1p[ORC_MAX_CN];
+        const orc_pyramid *l0[ORC_MAX_CN], *r0[ORC_MAX_CN], *l1[ORC_MAX_CN], *r1[ORC_MAX_CN];
+        build_plane_pyramids(L1, w, h, cn, c, pl1p);                                 /* :200 */
+        build_plane_pyramids(R1, w, h, cn, c, pr1p);                                 /* :201 */
+        for (k = 0; k < cn; k++) { l0[k] = &vo->pyrL0[k]; r0[k] = &vo->pyrR0[k]; l1[k] = &pl1p[k]; r1[k] = &pr1p[k]; }
+        orc_circular_match_cn(cn, l0, r0, l1, r1, n, pl0, pl1, pr1, pr0, plc, ok, c);   /* :203-230 */
+        for (k = 0; k < cn; k++) {
+            orc_pyramid_free(&vo->pyrL0[k]); orc_pyramid_free(&vo->pyrR0[k]);
+            vo->pyrL0[k] = pl1p[k]; vo->pyrR0[k] = pr1p[k];                          /* :231-232 */
+        }
         compact_features(vo, ok, n);                                                 /* :233 */
         compact_f(pl0, 2, n, ok); compact_f(pl1, 2, n, ok); compact_f(pr1, 2, n, ok); nt = compact_f(pr0, 2, n, ok);   /* :234-238 */
         st->n_after_circular = nt;

@@ -304,11 +304,15 @@ class VisualOdometry:
         lib().orc_vo_set_projection(self.h, _p(Pl), _p(Pr))
 
     def stereo_callback(self, left, right):
-        left, right = u8img(left), u8img(right)
-        h, w = left.shape
+        """(H, W) gray images, or (H, W, 3) interleaved BGR — what the reference CLI feeds."""
+        left = np.ascontiguousarray(left, dtype=np.uint8); right = np.ascontiguousarray(right, dtype=np.uint8)
+        assert left.shape == right.shape and (left.ndim == 2 or (left.ndim == 3 and left.shape[2] == 3))
+        h, w = left.shape[:2]
+        cn = 1 if left.ndim == 2 else 3
         T = np.zeros(16)
         st = OrcFrameStats()
-        ok = lib().orc_vo_stereo_callback(self.h, _p(left), _p(right), w, h, w, _p(T), C.byref(st))
+        ok = lib().orc_vo_stereo_callback_cn(self.h, _p(left), _p(right), w, h, w * cn, cn, _p(T), C.byref(st))
+        assert ok >= 0, "channel count changed between frames"
         self.stats = st
         return bool(ok), T.reshape(4, 4)
 
