@@ -53,6 +53,11 @@ typedef struct {
     double lk_epsilon;                    /* vo.cpp:184 1e-4 */
     float ransac_confidence;              /* vo.cpp:295 0.98f */
     int max_features;                     /* build preset (not in the reference): 0 = unlimited */
+    int channels;                         /* 1 (default): 8-bit single-channel images, what the ROS path delivers (stereo_vo.cpp:9).
+                                           * 3: interleaved 8-bit BGR, what the reference CLI really feeds (main.cpp:38-46 returns the
+                                           * colour Mats): cv::FAST then walks the first `width` BYTES of every row (it has no channel
+                                           * check), pyramids and LK are 3-channel.  Frame pipeline only (svo_process*, svo_submit_batch);
+                                           * strides are in bytes.  Reproduces the trajectory the reference recorded for run1/. */
 } svo_config;
 
 /* Per-frame counters — the numbers the reference prints at vo.cpp:226,239,326,331,365,108-110,128-130. */

@@ -75,6 +75,7 @@ typedef struct {
     float ransac_confidence;     /* vo.cpp:295 = 0.98f (a float32 in the reference) */
     int max_features;            /* build preset, NOT in the reference: 0 = unlimited; >0 keeps the
                                     first max_features of the bucketed set */
+    int channels;                /* 1 = single-channel input (default), 3 = interleaved BGR as the reference CLI feeds (B-1) */
 } orc_config;
 
 void orc_config_default(orc_config* c);

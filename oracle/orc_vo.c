@@ -29,7 +29,7 @@ void orc_config_default(orc_config* c) {
     c->ransac_iterations = 100; c->optical_flow_min_eig_threshold = 0.001;
     c->circular_matching_success_threshold = .15; c->max_translation_norm = .1; c->max_rotation_norm = .5;
     c->win_w = 10; c->win_h = 10; c->max_level = 3; c->lk_max_count = 30; c->lk_epsilon = 0.0001;
-    c->ransac_confidence = 0.98f; c->max_features = 0;
+    c->ransac_confidence = 0.98f; c->max_features = 0; c->channels = 1;
 }
 
 struct orc_vo {
@@ -140,7 +140,7 @@ static void build_plane_pyramids(const uint8_t* img, int w, int h, int cn, const
 
 int orc_vo_stereo_callback(orc_vo* vo, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
                            double T_out[16], orc_frame_stats* st) {
-    return orc_vo_stereo_callback_cn(vo, left, right, w, h, stride, 1, T_out, st);
+    return orc_vo_stereo_callback_cn(vo, left, right, w, h, stride, vo->cfg.channels == 3 ? 3 : 1, T_out, st);
 }
 
 int orc_vo_stereo_callback_cn(orc_vo* vo, const uint8_t* left, const uint8_t* right, int w, int h, int stride, int cn,

@@ -45,7 +45,7 @@ class SvoConfig(C.Structure):
         ("optical_flow_min_eig_threshold", C.c_double), ("circular_matching_success_threshold", C.c_double),
         ("max_translation_norm", C.c_double), ("max_rotation_norm", C.c_double),
         ("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int), ("lk_max_count", C.c_int),
-        ("lk_epsilon", C.c_double), ("ransac_confidence", C.c_float), ("max_features", C.c_int),
+        ("lk_epsilon", C.c_double), ("ransac_confidence", C.c_float), ("max_features", C.c_int), ("channels", C.c_int),
     ]
 
 
@@ -100,4 +100,12 @@ def u8img(img):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     if img.ndim != 2:
         raise ValueError("single-channel 8-bit image expected (the ROS path delivers MONO8, src/stereo_vo.cpp:9)")
+    return img
+
+
+def u8frame(img):
+    """A frame for the frame pipeline: (H, W) gray, or (H, W, 3) interleaved BGR as the reference CLI feeds it (svo.h: channels)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if not (img.ndim == 2 or (img.ndim == 3 and img.shape[2] == 3)):
+        raise ValueError("8-bit (H, W) or (H, W, 3) image expected")
     return img

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import SvoConfig, SvoFrameStats, check, default_config, lib, ptr, u8img
+from ._lib import SvoConfig, SvoFrameStats, check, default_config, lib, ptr, u8frame, u8img
 
 # the reference's constants (include/vo.h:53-127) for callers that used them by name
 BUCKET_START_ROW, BUCKETS_ALONG_HEIGHT, BUCKETS_ALONG_WIDTH, FEATURES_PER_BUCKET = 4, 92, 160, 1
@@ -262,13 +262,15 @@ class BatchVisualOdometry:
 
     def stereo_callback_batch(self, lefts, rights):
         """lists of n_seq host images -> (ok (n_seq,) bool, T (n_seq,4,4) f64)."""
-        L = [u8img(i) for i in lefts]; R = [u8img(i) for i in rights]
+        L = [u8frame(i) for i in lefts]; R = [u8frame(i) for i in rights]
         assert len(L) == self.n_seq and len(R) == self.n_seq
+        cn = max(1, self.cfg.channels)
+        assert all(i.shape == (self.height, self.width) + ((3,) if cn == 3 else ()) for i in L + R), "image shape / channels"
         lp = (C.c_void_p * self.n_seq)(*[i.ctypes.data for i in L])
         rp = (C.c_void_p * self.n_seq)(*[i.ctypes.data for i in R])
         T = np.zeros((self.n_seq, 16)); ok = np.zeros(self.n_seq, np.int32)
         st = (SvoFrameStats * self.n_seq)()
-        check(lib.svo_process_batch(self._h, lp, rp, self.width, 0, ptr(T), ptr(ok), st))
+        check(lib.svo_process_batch(self._h, lp, rp, self.width * cn, 0, ptr(T), ptr(ok), st))
         self.stats = list(st)
         return ok.astype(bool), T.reshape(self.n_seq, 4, 4)
 
@@ -332,14 +334,18 @@ class VisualOdometry(BatchVisualOdometry):
             super().initalize_projection_matricies(leftCameraProjection, rightCameraProjection)
 
     def stereo_callback(self, image_left, image_right):
-        L, R = u8img(image_left), u8img(image_right)
-        if not self._created:                         # the reference learns the image size from the first frame
-            super().__init__(L.shape[1], L.shape[0], 1, *self._args)
+        L, R = u8frame(image_left), u8frame(image_right)
+        if not self._created:                         # the reference learns the image size (and type) from the first frame
+            cfg, device = self._args
+            if L.ndim == 3:                           # colour Mats, as the reference CLI feeds them (main.cpp:38-46)
+                cfg = cfg if cfg is not None else default_config()
+                cfg.channels = 3
+            super().__init__(L.shape[1], L.shape[0], 1, cfg, device)
             self._created = True
             if self._P is not None:
                 super().initalize_projection_matricies(*self._P)
         T = np.zeros(16)
         st = SvoFrameStats()
-        rc = check(lib.svo_process(self._h, ptr(L), ptr(R), L.shape[1], ptr(T), C.byref(st)))
+        rc = check(lib.svo_process(self._h, ptr(L), ptr(R), L.strides[0], ptr(T), C.byref(st)))
         self.stats = st
         return bool(rc), T.reshape(4, 4)

@@ -39,7 +39,7 @@ extern "C" void svo_config_default(svo_config* c) {
     c->ransac_iterations = 100; c->optical_flow_min_eig_threshold = 0.001;
     c->circular_matching_success_threshold = .15; c->max_translation_norm = .1; c->max_rotation_norm = .5;
     c->win_w = 10; c->win_h = 10; c->max_level = 3; c->lk_max_count = 30; c->lk_epsilon = 0.0001;
-    c->ransac_confidence = 0.98f; c->max_features = 0;
+    c->ransac_confidence = 0.98f; c->max_features = 0; c->channels = 1;
 }
 
 // cv::buildOpticalFlowPyramid's level rule: level 0 always, stop as soon as
@@ -97,6 +97,9 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     if (width <= cfg.win_w || height <= cfg.win_h) return fail_arg("image must be larger than the LK window");
     if (cfg.features_per_bucket != 1) return fail_arg("the frame pipeline supports features_per_bucket == 1 (use svo_bucket_filter for other capacities)");
     if (cfg.buckets_along_height < 1 || cfg.buckets_along_width < 1 || cfg.ransac_iterations < 1) return fail_arg("bad bucket grid / ransac_iterations");
+    if (cfg.channels == 0) cfg.channels = 1;
+    if (cfg.channels != 1 && cfg.channels != 3) return fail_arg("channels must be 1 or 3");
+    if (!lk_window_supported_cn(cfg.win_w, cfg.channels)) return fail_arg("this LK window is not built for 3-channel input (7, 10, 15, 21 are)");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail_arg("no such HIP device");
@@ -106,7 +109,7 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     DevBuffers& d = c->d;
-    d.B = n_seq; d.cfg = cfg; d.K = cfg.ransac_iterations;
+    d.B = n_seq; d.cfg = cfg; d.K = cfg.ransac_iterations; d.CN = cfg.channels;
     d.NB = cfg.buckets_along_height * cfg.buckets_along_width;
     d.bucket_h = (height + cfg.buckets_along_height - 1) / cfg.buckets_along_height;     // feature_set.cpp:91-93,103-104
     d.bucket_w = (width + cfg.buckets_along_width - 1) / cfg.buckets_along_width;
@@ -120,7 +123,8 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     int rc;
 #define ALLOC(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != SVO_OK) return rc;
     ALLOC(d.st, B);
-    ALLOC(d.pyr, B * 6 * (size_t)d.geom.pyr_bytes + 256);        // + slack: the LK kernel's unaligned dword loads may read a few bytes past a row
+    ALLOC(d.pyr, B * 6 * (size_t)d.CN * (size_t)d.geom.pyr_bytes + 256);   // + slack: the LK kernel's unaligned dword loads may read a few bytes past a row
+    if (d.CN == 3) ALLOC(d.fastimg, B * 3 * (size_t)width * (size_t)height + 256);
     for (int k = 0; k < 2; k++) { ALLOC(d.feat_xy[k], B * CAP); ALLOC(d.feat_age[k], B * CAP); ALLOC(d.feat_str[k], B * CAP); }
     ALLOC(d.bucket_keys, B * (size_t)d.NB);
     ALLOC(d.pl0, B * CAP); ALLOC(d.pl1, B * CAP); ALLOC(d.pr1, B * CAP); ALLOC(d.pr0, B * CAP); ALLOC(d.plc, B * CAP);
@@ -253,7 +257,7 @@ static int collect_frame(svo_context* c, double* T_out, int* ok_out, svo_frame_s
 extern "C" int svo_submit_batch(svo_context* c, const uint8_t* const* left_dev, const uint8_t* const* right_dev, int stride) {
     if (!c || !left_dev || !right_dev) return fail_arg("null argument");
     if (!c->projection_set) { g_err = "svo_set_projection must be called first"; return SVO_ERR_STATE; }
-    if (stride < c->d.geom.W) return fail_arg("stride < width");
+    if (stride < c->d.geom.W * c->d.CN) return fail_arg("stride < width * channels");
     HIPCHK(hipSetDevice(c->device));
     return enqueue_frame(c, left_dev, right_dev, stride);
 }
@@ -268,7 +272,7 @@ extern "C" int svo_process_batch(svo_context* c, const uint8_t* const* left, con
                                  int images_on_device, double* T_out, int* ok_out, svo_frame_stats* stats) {
     if (!c || !left || !right) return fail_arg("null argument");
     if (!c->projection_set) { g_err = "svo_set_projection must be called first"; return SVO_ERR_STATE; }
-    if (stride < c->d.geom.W) return fail_arg("stride < width");
+    if (stride < c->d.geom.W * c->d.CN) return fail_arg("stride < width * channels");
     if (c->inflight != 0) { g_err = "svo_process_batch with frames in flight"; return SVO_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
     const int B = c->d.B, W = c->d.geom.W, H = c->d.geom.H;
@@ -277,7 +281,7 @@ extern "C" int svo_process_batch(svo_context* c, const uint8_t* const* left, con
         rc = enqueue_frame(c, left, right, stride);
     } else {
         // the caller's buffers are only borrowed for the duration of the call: copy to the device first (SURVEY.md §8b "Ownership")
-        const size_t img = (size_t)W * H;
+        const size_t rowb = (size_t)W * c->d.CN, img = rowb * H;
         if (!c->staging) HIPCHK(hipMalloc((void**)&c->staging, img * 2 * B));
         if (!c->h_staging) HIPCHK(hipHostMalloc((void**)&c->h_staging, img * 2 * B));
         // rows are packed into pinned memory on the CPU (handles any stride), then ONE contiguous async H2D copy
@@ -286,12 +290,12 @@ extern "C" int svo_process_batch(svo_context* c, const uint8_t* const* left, con
         for (int i = 0; i < B; i++) {
             if (!left[i] || !right[i]) return fail_arg("null image pointer");
             uint8_t* hl = c->h_staging + img * i; uint8_t* hr = c->h_staging + img * (B + i);
-            if (stride == W) { memcpy(hl, left[i], img); memcpy(hr, right[i], img); }
-            else for (int y = 0; y < H; y++) { memcpy(hl + (size_t)y * W, left[i] + (size_t)y * stride, W); memcpy(hr + (size_t)y * W, right[i] + (size_t)y * stride, W); }
+            if ((size_t)stride == rowb) { memcpy(hl, left[i], img); memcpy(hr, right[i], img); }
+            else for (int y = 0; y < H; y++) { memcpy(hl + (size_t)y * rowb, left[i] + (size_t)y * stride, rowb); memcpy(hr + (size_t)y * rowb, right[i] + (size_t)y * stride, rowb); }
             lp[i] = c->staging + img * i; rp[i] = c->staging + img * (B + i);
         }
         HIPCHK(hipMemcpyAsync(c->staging, c->h_staging, img * 2 * B, hipMemcpyHostToDevice, c->stream));
-        rc = enqueue_frame(c, lp.data(), rp.data(), W);
+        rc = enqueue_frame(c, lp.data(), rp.data(), (int)rowb);
     }
     if (rc != SVO_OK) return rc;
     return collect_frame(c, T_out, ok_out, stats);
@@ -457,6 +461,7 @@ extern "C" int svo_append_features_from_image(int device, const svo_config* cfg_
                                               int fast_threshold, int cap, int* n_io, float* xy, int* ages, int* strengths) {
     if (!img || !n_io || *n_io < 0 || stride < w || cap < *n_io) return fail_arg("bad arguments");
     svo_config cfg; if (cfg_in) cfg = *cfg_in; else svo_config_default(&cfg);
+    cfg.channels = 1;                                                             // stage entry points are single-channel
     CtxGuard g; int rc = ctx_create(&cfg, device, 1, w, h, *n_io, &g.c); if (rc != SVO_OK) return rc;
     svo_context* c = g.c;
     const int n = *n_io;
@@ -537,7 +542,7 @@ extern "C" int svo_circular_match(int device, const svo_config* cfg_in, const ui
     if (!l0 || !r0 || !l1 || !r1 || n < 0 || stride < w) return fail_arg("bad arguments");
     if (n > 0 && (!pl0 || !pl1 || !pr1 || !pr0 || !pl0_circle || !ok)) return fail_arg("null arrays");
     svo_config cfg; if (cfg_in) cfg = *cfg_in; else svo_config_default(&cfg);
-    cfg.max_features = 0;
+    cfg.max_features = 0; cfg.channels = 1;
     CtxGuard g; int rc = ctx_create(&cfg, device, 1, w, h, n, &g.c); if (rc != SVO_OK) return rc;
     svo_context* c = g.c;
     if (n == 0) return SVO_OK;                                                    // vo.cpp:179-181

@@ -44,12 +44,15 @@ struct FrameResult { double T[16]; int ok; svo_frame_stats stats; };
 // All device buffers of a context (B sequences, capacity CAP features each).
 struct DevBuffers {
     int B, CAP, NB;                            // NB = buckets_along_height * buckets_along_width
+    int CN;                                    // image channels: 1, or 3 (interleaved BGR in, one pyramid per colour plane inside)
     int K;                                     // ransac_iterations
     Geometry geom;
     svo_config cfg;
     int bucket_h, bucket_w;
     SeqState* st;                              // [B]
-    uint8_t* pyr;                              // [B][3 slots][2 cams][pyr_bytes]
+    uint8_t* pyr;                              // [B][3 slots][2 cams][CN planes][pyr_bytes]
+    uint8_t* fastimg;                          // CN == 3 only: [B][3 slots][W*H] the first W bytes of every interleaved left row —
+                                               // the single-channel 'image' cv::FAST sees in a BGR Mat
     float2* feat_xy[2]; int* feat_age[2]; int* feat_str[2];   // [B][CAP] each, double-buffered
     unsigned long long* bucket_keys;           // [B][NB]
     float2 *pl0, *pl1, *pr1, *pr0, *plc;       // [B][CAP] raw LK outputs
@@ -65,13 +68,17 @@ struct DevBuffers {
     const uint8_t** img_ptrs;                  // [SVO_RING][2][B] device array of source image pointers
 };
 
+// plane 0 of the pyramid of (sequence, slot, camera); plane k follows at + k * geom.pyr_bytes
 __host__ __device__ inline size_t pyr_index(const DevBuffers& d, int seq, int slot, int cam) {
-    return ((size_t)(seq * 3 + slot) * 2 + cam) * (size_t)d.geom.pyr_bytes;
+    return ((size_t)(seq * 3 + slot) * 2 + cam) * (size_t)d.CN * (size_t)d.geom.pyr_bytes;
+}
+__host__ __device__ inline size_t fastimg_index(const DevBuffers& d, int seq, int slot) {
+    return (size_t)(seq * 3 + slot) * (size_t)d.geom.W * (size_t)d.geom.H;
 }
 
 // ---- launchers (each enqueues on `s`; none synchronises) ----
 void launch_frame_begin(const DevBuffers& d, hipStream_t s);
-void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs /* [2][B] device array */, int stride, hipStream_t s);
+void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs /* [2][B] device array */, int stride_bytes, hipStream_t s);
 void launch_pyramid(const DevBuffers& d, hipStream_t s);
 void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s);   // pass 0: FAST_THRESHOLD, pass 1: /4 if needed; th_override >= 0 replaces it
 void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t s);      // grid_n = max features that can enter LK
@@ -92,3 +99,4 @@ void launch_lk_single(const DevBuffers& d, int slotA, int camA, int slotB, int c
                       uint8_t* status, hipStream_t s);
 void launch_find_close(int n, const float2* a, const float2* b, float thr, uint8_t* ok, hipStream_t s);
 bool lk_window_supported(int win);
+bool lk_window_supported_cn(int win, int cn);

@@ -78,7 +78,31 @@ __global__ __launch_bounds__(256) void k_ingest(DevBuffers d, const uint8_t* con
     }
 }
 
+// Colour form: interleaved BGR rows -> three planes (level 0 of the three per-plane pyramids) and, for the left camera, the
+// W x H byte image made of the first W bytes of every row, which is what cv::FAST scans in a 3-channel Mat.
+__global__ __launch_bounds__(256) void k_ingest_bgr(DevBuffers d, const uint8_t* const* srcs, int stride) {
+    const int seq = blockIdx.z, cam = blockIdx.y;
+    const int W = d.geom.W, H = d.geom.H;
+    const int total = W * H;
+    const uint8_t* src = srcs[cam * d.B + seq];
+    const int slot = d.st[seq].slot_t1;
+    uint8_t* p0 = d.pyr + pyr_index(d, seq, slot, cam);
+    uint8_t* fi = d.fastimg + fastimg_index(d, seq, slot);
+    const size_t pb = (size_t)d.geom.pyr_bytes;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        const uint8_t* sp = src + (size_t)y * stride;
+        p0[i] = sp[3 * x]; p0[pb + i] = sp[3 * x + 1]; p0[2 * pb + i] = sp[3 * x + 2];
+        if (cam == 0) fi[i] = sp[x];
+    }
+}
+
 void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride, hipStream_t st) {
+    if (d.CN == 3) {
+        int gx = (d.geom.W * d.geom.H + 255) / 256; if (gx > 2048) gx = 2048;
+        hipLaunchKernelGGL(k_ingest_bgr, dim3(gx, 2, d.B), dim3(256), 0, st, d, left_right_dev_ptrs, stride);
+        return;
+    }
     int total = ((d.geom.W + 3) >> 2) * d.geom.H;
     int gx = (total + 255) / 256; if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(k_ingest, dim3(gx, 2, d.B), dim3(256), 0, st, d, left_right_dev_ptrs, stride);
@@ -92,9 +116,10 @@ void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptr
 #define PD_TW 32
 #define PD_TH 8
 __global__ __launch_bounds__(256) void k_pyrdown(DevBuffers d, int level) {
-    const int seq = blockIdx.z / 2, cam = blockIdx.z & 1;
+    const int plane = blockIdx.z % d.CN, sc = blockIdx.z / d.CN;          // every colour plane is its own pyramid
+    const int seq = sc / 2, cam = sc & 1;
     const LevelInfo ls = d.geom.lv[level - 1], ld = d.geom.lv[level];
-    uint8_t* base = d.pyr + pyr_index(d, seq, d.st[seq].slot_t1, cam);
+    uint8_t* base = d.pyr + pyr_index(d, seq, d.st[seq].slot_t1, cam) + (size_t)plane * d.geom.pyr_bytes;
     const uint8_t* src = base + ls.off;
     uint8_t* dst = base + ld.off;
     constexpr int SW = 2 * PD_TW + 3, SH = 2 * PD_TH + 3;        // 67 x 19 source tile
@@ -137,7 +162,7 @@ __global__ __launch_bounds__(256) void k_pyrdown(DevBuffers d, int level) {
 
 void launch_pyramid(const DevBuffers& d, hipStream_t st) {
     for (int l = 1; l < d.geom.nlevels; l++) {
-        dim3 g((d.geom.lv[l].w + PD_TW - 1) / PD_TW, (d.geom.lv[l].h + PD_TH - 1) / PD_TH, d.B * 2);
+        dim3 g((d.geom.lv[l].w + PD_TW - 1) / PD_TW, (d.geom.lv[l].h + PD_TH - 1) / PD_TH, d.B * 2 * d.CN);
         hipLaunchKernelGGL(k_pyrdown, g, dim3(256), 0, st, d, l);
     }
 }
@@ -218,7 +243,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* img_single, int w_s
         const SeqState& s = d.st[seq];
         if (pass == 0 ? !s.active : !s.do_second) return;
         W = d.geom.W; H = d.geom.H;
-        img = d.pyr + pyr_index(d, seq, s.slot_img_t0, 0);       // FAST runs on the PREVIOUS left image (vo.cpp:325)
+        // FAST runs on the PREVIOUS left image (vo.cpp:325); for a BGR context on the byte image cv::FAST really scans
+        img = d.CN == 3 ? d.fastimg + fastimg_index(d, seq, s.slot_img_t0) : d.pyr + pyr_index(d, seq, s.slot_img_t0, 0);
     } else { W = w_single; H = h_single; img = img_single; }
     if (threshold < 0) threshold = 0;
     if (threshold > 255) threshold = 255;

@@ -210,14 +210,18 @@ __device__ __forceinline__ void load_pairs(const uint8_t* __restrict__ p, unsign
 // SURVEY.md Appendix A.3).  (px,py) -> (outx,outy), status.  Written as plain SIMT code: every "per feature" quantity
 // lives in a VGPR and is identical across the G lanes of the feature's group; control flow diverges between groups and
 // is handled by the exec mask.  segrow / segxs / segon describe the SPL window segments this lane owns.
-template <int W, int G>
-__device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB,
+// CN = image channels: the window sums of LKTrackerInvoker run over every channel of every pixel (x < winSize.width*cn).
+// Each colour plane is its own single-channel pyramid (plane k at pyr + k * pstride); the (plane, segment) pairs a lane owns
+// are flattened into one index kk = plane * SPL + segment, so CN = 3 simply triples the per-lane pixel arrays.
+template <int W, int G, int CN>
+__device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, size_t pstride,
                         float px, float py, float& outx, float& outy, int& status, const LkCrit& crit,
                         const LkSegs<LkLayout<W, G>::SPL>& sg) {
     using LL = LkLayout<W, G>;
     constexpr int PPL = LL::PPL, EXT = LL::EXT, NS = LL::NS, NB = LL::NB, SPL = LL::SPL;
-    constexpr int PRE = lk_presplit_steps(PPL * SPL);
-    constexpr float NARROW_LIMIT = (float)(0.95 * 4611686018427387904.0 / (8160.0 * 8160.0 * W * W));
+    constexpr int KS = SPL * CN;                                        // (plane, segment) pairs per lane
+    constexpr int PRE = lk_presplit_steps(PPL * KS);
+    constexpr float NARROW_LIMIT = (float)(0.95 * 4611686018427387904.0 / (8160.0 * 8160.0 * W * W * CN));
     const float half = (W - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
     const int top = g.nlevels - 1;
@@ -251,17 +255,19 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         // shift unit, so folding it in is exact); and the derivatives as packed signed 16-bit pairs of adjacent pixels, the
         // operand layout of v_dot2_i32_i16: one instruction multiplies two mismatches with two derivatives and accumulates.
         constexpr int NPR = (PPL + 1) / 2;
-        int Kr[SPL][PPL];
-        unsigned Ixp[SPL][NPR], Iyp[SPL][NPR];
+        int Kr[KS][PPL];
+        unsigned Ixp[KS][NPR], Iyp[KS][NPR];
         int pA11 = 0, pA12 = 0, pA22 = 0;
         const bool interior = ipx >= 1 && ipx + EXT + 1 < L.w && ipy >= 1 && ipy + W + 1 < L.h;
 #pragma unroll
-        for (int k = 0; k < SPL; k++) {
+        for (int kk = 0; kk < KS; kk++) {
+            const int k = kk % SPL;
+            const uint8_t* __restrict__ Ap = A + (size_t)(kk / SPL) * pstride;       // this colour plane
             const int row = sg.row[k], xs = sg.xs[k];
             unsigned Ip[2][PPL], DXp[2][PPL], DYp[2][PPL];             // [row 0/1 of the bilinear][pixel]: packed pairs
             if (interior) {
                 unsigned Q[4][NS - 1];
-                const uint8_t* p = A + (size_t)(ipy - 1 + row) * L.w + (ipx - 1 + xs);
+                const uint8_t* p = Ap + (size_t)(ipy - 1 + row) * L.w + (ipx - 1 + xs);
 #pragma unroll
                 for (int r = 0; r < 4; r++) load_pairs<NS>(p + (size_t)r * L.w, Q[r]);
 #pragma unroll
@@ -292,7 +298,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 int sv[4][NS];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const uint8_t* rp = A + (size_t)reflect101(ipy - 1 + row + r, L.h) * L.w;
+                    const uint8_t* rp = Ap + (size_t)reflect101(ipy - 1 + row + r, L.h) * L.w;
 #pragma unroll
                     for (int c = 0; c < NS; c++) sv[r][c] = rp[reflect101(ipx - 1 + xs + c, L.w)];
                 }
@@ -326,21 +332,21 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             for (int j = 0; j < PPL; j++) {
                 const bool on = (EXT == W) || (xs + j < W);
                 const int iacc = dot2(Ip[1][j], w1, dot2(Ip[0][j], w0, 1 << (LK_WBITS - 6)));          // I = iacc >> (WBITS-5)
-                Kr[k][j] = (1 << (LK_WBITS - 6)) - (iacc & ~((1 << (LK_WBITS - 5)) - 1));
+                Kr[kk][j] = (1 << (LK_WBITS - 6)) - (iacc & ~((1 << (LK_WBITS - 5)) - 1));
                 const int ixval = dot2(DXp[1][j], wd1, dot2(DXp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
                 const int iyval = dot2(DYp[1][j], wd1, dot2(DYp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
                 ixv[j] = on ? ixval : 0; iyv[j] = on ? iyval : 0;
             }
 #pragma unroll
             for (int q = 0; q < NPR; q++) {
-                Ixp[k][q] = (2 * q + 1 < PPL) ? pack_lo16(ixv[2 * q], ixv[2 * q + 1]) : ((unsigned)ixv[2 * q] & 0xFFFFu);
-                Iyp[k][q] = (2 * q + 1 < PPL) ? pack_lo16(iyv[2 * q], iyv[2 * q + 1]) : ((unsigned)iyv[2 * q] & 0xFFFFu);
-                pA11 = dot2(Ixp[k][q], Ixp[k][q], pA11); pA12 = dot2(Ixp[k][q], Iyp[k][q], pA12); pA22 = dot2(Iyp[k][q], Iyp[k][q], pA22);
+                Ixp[kk][q] = (2 * q + 1 < PPL) ? pack_lo16(ixv[2 * q], ixv[2 * q + 1]) : ((unsigned)ixv[2 * q] & 0xFFFFu);
+                Iyp[kk][q] = (2 * q + 1 < PPL) ? pack_lo16(iyv[2 * q], iyv[2 * q + 1]) : ((unsigned)iyv[2 * q] & 0xFFFFu);
+                pA11 = dot2(Ixp[kk][q], Ixp[kk][q], pA11); pA12 = dot2(Ixp[kk][q], Iyp[kk][q], pA12); pA22 = dot2(Iyp[kk][q], Iyp[kk][q], pA22);
             }
         }
         float As[3];
         { const int pa[3] = {pA11, pA12, pA22}; group_sums_to_float<G, 3, PRE>(pa, As); }
-        // |sum diff*Ix| <= 8160 * sqrt(W^2 * sum Ix^2) (Cauchy-Schwarz): below 2^31 when sum Ix^2 < 2^62 / (8160^2 W^2); 5 % margin
+        // |sum diff*Ix| <= 8160 * sqrt(CN W^2 * sum Ix^2) (Cauchy-Schwarz): below 2^31 when sum Ix^2 < 2^62 / (8160^2 CN W^2); 5 % margin
         // covers the float rounding of As.  Then the mismatch sums never leave int32 and take the narrow reduction.
         const bool narrow = As[0] < NARROW_LIMIT && As[2] < NARROW_LIMIT;
         const float A11 = As[0] * FLT_SCALE, A12 = As[1] * FLT_SCALE, A22 = As[2] * FLT_SCALE;
@@ -357,27 +363,29 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         // a pixel and touch no memory.
         int j = 0;
         float pdx = 0.f, pdy = 0.f;
-        unsigned P0[SPL][PPL], P1[SPL][PPL];
+        unsigned P0[KS][PPL], P1[KS][PPL];
         auto load_window = [&](int inx, int iny) __attribute__((always_inline)) {
             if (inx >= 0 && inx + EXT < L.w && iny >= 0 && iny + W < L.h) {
 #pragma unroll
-                for (int k = 0; k < SPL; k++) {
-                    const uint8_t* p = Bm + (size_t)(iny + sg.row[k]) * L.w + (inx + sg.xs[k]);
-                    load_pairs<NB>(p, P0[k]);
-                    load_pairs<NB>(p + L.w, P1[k]);
+                for (int kk = 0; kk < KS; kk++) {
+                    const int k = kk % SPL;
+                    const uint8_t* p = Bm + (size_t)(kk / SPL) * pstride + (size_t)(iny + sg.row[k]) * L.w + (inx + sg.xs[k]);
+                    load_pairs<NB>(p, P0[kk]);
+                    load_pairs<NB>(p + L.w, P1[kk]);
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < SPL; k++) {
+                for (int kk = 0; kk < KS; kk++) {
+                    const int k = kk % SPL;
                     int jb[2][NB];
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
-                        const uint8_t* rp = Bm + (size_t)reflect101(iny + sg.row[k] + r, L.h) * L.w;
+                        const uint8_t* rp = Bm + (size_t)(kk / SPL) * pstride + (size_t)reflect101(iny + sg.row[k] + r, L.h) * L.w;
 #pragma unroll
                         for (int c = 0; c < NB; c++) jb[r][c] = rp[reflect101(inx + sg.xs[k] + c, L.w)];
                     }
 #pragma unroll
-                    for (int c = 0; c < PPL; c++) { P0[k][c] = pack16(jb[0][c], jb[0][c + 1]); P1[k][c] = pack16(jb[1][c], jb[1][c + 1]); }
+                    for (int c = 0; c < PPL; c++) { P0[kk][c] = pack16(jb[0][c], jb[0][c + 1]); P1[kk][c] = pack16(jb[1][c], jb[1][c + 1]); }
                 }
             }
         };
@@ -386,20 +394,20 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             lk_weights(nx - fx0, ny - fy0, w0, w1);
             int pb1 = 0, pb2 = 0;
 #pragma unroll
-            for (int k = 0; k < SPL; k++) {
+            for (int kk = 0; kk < KS; kk++) {
                 int dv[PPL];
                 // J - I, |.| <= 8160; three sweeps so that dependent dot instructions are PPL instructions apart
 #pragma unroll
-                for (int jj = 0; jj < PPL; jj++) dv[jj] = dot2_keep(P0[k][jj], w0, Kr[k][jj]);
+                for (int jj = 0; jj < PPL; jj++) dv[jj] = dot2_keep(P0[kk][jj], w0, Kr[kk][jj]);
 #pragma unroll
-                for (int jj = 0; jj < PPL; jj++) dv[jj] = dot2(P1[k][jj], w1, dv[jj]);
+                for (int jj = 0; jj < PPL; jj++) dv[jj] = dot2(P1[kk][jj], w1, dv[jj]);
 #pragma unroll
                 for (int jj = 0; jj < PPL; jj++) dv[jj] >>= (LK_WBITS - 5);
 #pragma unroll
                 for (int q = 0; q < NPR; q++) {
                     // masked pixels (and the unpaired upper half) have Ix = Iy = 0: whatever mismatch they see contributes an exact zero
                     const unsigned dp = (2 * q + 1 < PPL) ? pack_lo16(dv[2 * q], dv[2 * q + 1]) : (unsigned)dv[2 * q];
-                    pb1 = dot2(dp, Ixp[k][q], pb1); pb2 = dot2(dp, Iyp[k][q], pb2);
+                    pb1 = dot2(dp, Ixp[kk][q], pb1); pb2 = dot2(dp, Iyp[kk][q], pb2);
                 }
             }
             float bs[2];
@@ -508,7 +516,7 @@ __device__ __forceinline__ LkCrit make_crit(const svo_config& c) {
 #define LK_MAP_STRIPE 0
 #define LK_MAP_AFFINE 1
 #define LK_MAP_INTERLEAVED 2
-template <int W, int G>
+template <int W, int G, int CN>
 __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mode, int chunk) {
     constexpr int FPW = 64 / G;                                       // features per wave (= per block)
     int seq, fb;
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mo
             const uint8_t* A = pass == 0 ? L0 : pass == 1 ? L1 : pass == 2 ? R1 : R0;      // vo.cpp:203, 206, 209, 213
             const uint8_t* Bq = pass == 0 ? L1 : pass == 1 ? R1 : pass == 2 ? R0 : L0;
             float2 q; int st;
-            lk_pass<W, G>(d.geom, A, Bq, cur.x, cur.y, q.x, q.y, st, crit, sg);
+            lk_pass<W, G, CN>(d.geom, A, Bq, (size_t)d.geom.pyr_bytes, cur.x, cur.y, q.x, q.y, st, crit, sg);
             if (pass == 0) { p1 = q; st0 = st; } else if (pass == 1) { p2 = q; st1 = st; } else if (pass == 2) { p3 = q; st2 = st; } else { p4 = q; st3 = st; }
             cur = q;
         }
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(64) void k_lk_single(DevBuffers d, int slotA, int c
         const int idx = base + slot;
         if (idx >= n) continue;
         float2 p = prev[idx], q; int st;
-        lk_pass<W, G>(d.geom, A, Bp, p.x, p.y, q.x, q.y, st, crit, sg);
+        lk_pass<W, G, 1>(d.geom, A, Bp, 0, p.x, p.y, q.x, q.y, st, crit, sg);
         if (threadIdx.x % G == 0) { next[idx] = q; status[idx] = (uint8_t)st; }
     }
 }
@@ -607,9 +615,20 @@ static int lk_xcd_mapping() { static int v = -1; if (v < 0) { const char* e = ge
 // SVO_LK_G=<lanes> for measurement.
 #define LK_FOR_EACH_WINDOW(X) X(7, 16) X(10, 16) X(15, 32) X(15, 64) X(21, 64) X(21, 32) X(31, 64)
 
+// 3-channel (BGR) instantiations: one per window, at the window's default lanes-per-feature (w = 31 would need 48 pixels of
+// template and search window per lane, more registers than a wave has)
+#define LK_FOR_EACH_WINDOW_CN3(X) X(7, 16) X(10, 16) X(15, 32) X(21, 64)
+
 bool lk_window_supported(int win) {
 #define CHK(Wn, Gn) if (win == Wn) return true;
     LK_FOR_EACH_WINDOW(CHK)
+#undef CHK
+    return false;
+}
+bool lk_window_supported_cn(int win, int cn) {
+    if (cn == 1) return lk_window_supported(win);
+#define CHK(Wn, Gn) if (win == Wn) return true;
+    if (cn == 3) { LK_FOR_EACH_WINDOW_CN3(CHK) }
 #undef CHK
     return false;
 }
@@ -633,10 +652,22 @@ void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
         gx = (gx + 8 * chunk - 1) / (8 * chunk) * (8 * chunk);   /* blocks per sequence: whole runs on every XCD */ \
         const int rounds = (d.B + 7) / 8; \
         const unsigned blocks = mode == LK_MAP_AFFINE ? (unsigned)gx * 8u * (unsigned)rounds : (unsigned)gx * (unsigned)d.B; \
-        hipLaunchKernelGGL((k_lk_chain<Wn, Gn>), dim3(blocks), dim3(64), 0, st, d, gx, mode, chunk); \
+        hipLaunchKernelGGL((k_lk_chain<Wn, Gn, CNn>), dim3(blocks), dim3(64), 0, st, d, gx, mode, chunk); \
         return; }
-    LK_FOR_EACH_WINDOW(LAUNCH)
+#define CNn 1
+    if (d.CN == 1) { LK_FOR_EACH_WINDOW(LAUNCH) }
+#undef CNn
 #undef LAUNCH
+    // 3-channel contexts: the window's default group size only
+#define LAUNCH3(Wn, Gn) if (d.cfg.win_w == Wn) { int gx = (grid_n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
+        const int chunk = lk_chunk(); \
+        gx = (gx + 8 * chunk - 1) / (8 * chunk) * (8 * chunk); \
+        const int rounds = (d.B + 7) / 8; \
+        const unsigned blocks = mode == LK_MAP_AFFINE ? (unsigned)gx * 8u * (unsigned)rounds : (unsigned)gx * (unsigned)d.B; \
+        hipLaunchKernelGGL((k_lk_chain<Wn, Gn, 3>), dim3(blocks), dim3(64), 0, st, d, gx, mode, chunk); \
+        return; }
+    if (d.CN == 3) { LK_FOR_EACH_WINDOW_CN3(LAUNCH3) }
+#undef LAUNCH3
 }
 
 void launch_lk_single(const DevBuffers& d, int slotA, int camA, int slotB, int camB, int n, const float2* prev, float2* next,

@@ -29,7 +29,7 @@ class OrcConfig(C.Structure):
         ("optical_flow_min_eig_threshold", C.c_double), ("circular_matching_success_threshold", C.c_double),
         ("max_translation_norm", C.c_double), ("max_rotation_norm", C.c_double),
         ("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int), ("lk_max_count", C.c_int),
-        ("lk_epsilon", C.c_double), ("ransac_confidence", C.c_float), ("max_features", C.c_int),
+        ("lk_epsilon", C.c_double), ("ransac_confidence", C.c_float), ("max_features", C.c_int), ("channels", C.c_int),
     ]
 
 

@@ -91,3 +91,44 @@ def test_oracle_tracks_the_whole_recording():
     path = np.linalg.norm(np.diff(ref[:, :3], axis=0), axis=1).sum()
     assert sum(flags) == n - 1
     assert path > 3.5 and err.max() < 0.06 and np.sqrt((err ** 2).mean()) < 0.03       # 2.1 cm RMSE over a 4 m path
+
+
+# ------------------------------------------------------------------------------------------------ the HIP path
+def run_both_color(api, left, right, over=None):
+    """oracle and HIP path side by side on BGR frames: flags, counters, feature sets and track lists bit-exact."""
+    over = over or {}
+    ovo = orc.VisualOdometry(orc.default_config(**over)); ovo.initalize_projection_matricies(*syn.projection_matrices(syn.RUN1))
+    gvo = api.VisualOdometry(cfg=api.default_config(**over)); gvo.initalize_projection_matricies(*syn.projection_matrices(syn.RUN1))
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+    pose, track = np.eye(4), []
+    for k, (l, r) in enumerate(zip(left, right)):
+        ok_o, T_o = ovo.stereo_callback(l, r)
+        ok_g, T_g = gvo.stereo_callback(l, r)
+        so = {f[0]: getattr(ovo.stats, f[0]) for f in ovo.stats._fields_}
+        assert ok_o == ok_g and so == gvo.stats.as_dict(), (k, so, gvo.stats.as_dict())
+        fo, fg = ovo.features(), gvo.features()
+        assert np.array_equal(bits(fo[0]), bits(fg[0])) and np.array_equal(fo[1], fg[1]) and np.array_equal(fo[2], fg[2]), k
+        if k > 0:
+            to, tg = ovo.last_tracks(), gvo.last_tracks()
+            for key in ("pl0", "pr0", "pl1", "pr1"):
+                assert np.array_equal(bits(to[key]), bits(tg[key])), (k, key)
+            assert np.array_equal(to["inlier"], tg["inlier"]), k
+        assert np.abs(T_o - T_g).max() < 1e-6, k
+        pose = pose @ T_g; track.append(pose[:3, 3].copy())
+    return np.array(track)
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_the_reference_recording_on_bgr_input():
+    from stereo_visual_odometry_amd import api
+    left, right = fixture_frames()
+    track = run_both_color(api, left, right)
+    check_against_recording(track, recorded())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("win,lv", [(7, 2), (15, 3), (21, 2)])
+def test_bgr_parity_other_windows(win, lv):
+    from stereo_visual_odometry_amd import api
+    left, right = fixture_frames()
+    run_both_color(api, left[:6], right[:6], dict(win_w=win, win_h=win, max_level=lv))
