@@ -41,11 +41,12 @@ using Vec3d = std::array<double, 3>;
 using Mat44 = std::array<double, 16>;     // 4x4 row-major
 
 // 8-bit single-channel image view (what cv_bridge MONO8 delivers, reference src/stereo_vo.cpp:9)
-struct Image {
+struct Image {                                                        // the part of cv::Mat the path uses: 8-bit, 1 or 3 channels
     const uint8_t* data = nullptr;
-    int rows = 0, cols = 0, step = 0;
+    int rows = 0, cols = 0, step = 0;                                 // step in bytes
+    int channels = 1;                                                 // 3 = interleaved BGR, as cv::imread returns it (main.cpp:38-39)
     Image() {}
-    Image(const uint8_t* d, int r, int c, int s = 0) : data(d), rows(r), cols(c), step(s ? s : c) {}
+    Image(const uint8_t* d, int r, int c, int s = 0, int cn = 1) : data(d), rows(r), cols(c), step(s ? s : c * cn), channels(cn) {}
     bool empty() const { return !data || rows <= 0 || cols <= 0; }
 };
 
@@ -176,7 +177,9 @@ class VisualOdometry {                                               // include/
     // vo.h:333-334: (success, transform).  On failure the transform is the last successful one (identity at first).
     std::pair<bool, Mat44> stereo_callback(const Image& image_left, const Image& image_right) {
         if (image_left.empty() || image_right.empty()) throw std::runtime_error("stereo_callback: empty image");
-        if (!ctx_) {
+        if (image_left.channels != image_right.channels) throw std::runtime_error("stereo_callback: channel mismatch");
+        if (!ctx_) {                                                  // the reference learns size and type from the first frame
+            cfg_.channels = image_left.channels;
             svo_throw(svo_create(&cfg_, default_device(), 1, image_left.cols, image_left.rows, &ctx_));
             if (have_p_) svo_throw(svo_set_projection(ctx_, -1, leftCameraProjection_.data(), rightCameraProjection_.data()));
         }

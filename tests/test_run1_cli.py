@@ -77,7 +77,7 @@ def test_cli_on_run1_matches_api_oracle_and_recording(tmp_path):
         f.write("time,x,y,dx,dy\n")
         for row in d["gt_csv"]:
             f.write(",".join("%.9g" % v for v in row) + "\n")
-    out = subprocess.run([build_cli(), "400", str(folder)], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([build_cli(), "400", str(folder), "--gray", "1"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "processed 8 frame pairs" in out.stdout                  # stops cleanly at the first missing pair (B-12)
     rows = evaluate.read_result_csv(folder / "result.csv")
@@ -111,7 +111,7 @@ def test_cli_reads_both_calibration_key_styles(tmp_path):
     outs = []
     for name in ("plain.yaml", "orbslam.yaml"):
         res = tmp_path / (name + ".csv")
-        r = subprocess.run([build_cli(), "10", str(folder), "--calib", str(tmp_path / name), "--out", str(res)], capture_output=True, text=True, timeout=300)
+        r = subprocess.run([build_cli(), "10", str(folder), "--calib", str(tmp_path / name), "--out", str(res), "--gray", "1"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append(evaluate.read_result_csv(res))
     assert np.array_equal(outs[0], outs[1]) and outs[0].shape == (3, 5)

@@ -1,14 +1,18 @@
 // svo_cli — counterpart of the reference's CLI harness `vo <N_FRAMES> <folder>` (reference src/main.cpp:21-47,
 // 315-407) on top of the C++ facade / C-ABI.  SURVEY.md §8 f-1.
 //
-//   svo_cli <N_FRAMES> <folder> [--calib file.yaml] [--out result.csv] [--device d]
+//   svo_cli <N_FRAMES> <folder> [--calib file.yaml] [--out result.csv] [--device d] [--gray 1] [--identity-start 1]
 //
 // Reads folder/left/frameNNNNNN.{pgm,png} (6 digits, as `run1`; 4 digits + .jpg sets are not decodable here) and
 // folder/right/..., runs VisualOdometry::stereo_callback per pair, integrates frame_pose = frame_pose * T from the
 // 26-degree pitched initial pose (main.cpp:368-373, 396) and writes `x,y,z,gtx,gty` rows (main.cpp:346-348, 397-400),
-// reading folder/gt.csv with the reference's column quirk (main.cpp:336-344, 385-392).  Differences, on purpose:
-//   * images are converted to 8-bit gray (cv::cvtColor BGR2GRAY integer formula) — the reference computes the gray
-//     image and then passes the colour one (main.cpp:41-46);
+// reading folder/gt.csv with the reference's column quirk (main.cpp:336-344, 385-392).
+// Like the reference, the frames go in as 3-channel BGR: readImages computes a gray image and then returns the colour Mats
+// (main.cpp:38-46; cv::imread turns gray files into 3-channel ones too).  `--gray 1` converts with the
+// cv::cvtColor BGR2GRAY integer formula and runs the single-channel path instead (what the ROS node delivers).
+// `--identity-start 1` starts from the identity pose: the bundled run1/result.csv was recorded that way (it predates the
+// 26-degree pitch of main.cpp:368-373), and with it this tool reproduces that file (tests/test_run1_color.py).
+// Differences, on purpose:
 //   * the run stops cleanly at the first missing image pair (the reference throws on run1's frame 128, B-12);
 //   * calibration may come from a YAML file with either key style (stereo_vo.cpp:40-44 `fx:` or kitti00.yaml `Camera.fx:`);
 //     without --calib the hard-coded run1 projection of main.cpp:357-364 is used.
@@ -25,7 +29,7 @@
 #include "svo/visual_odometry.hpp"
 using namespace visual_odometry;
 
-struct Gray { int w = 0, h = 0; std::vector<uint8_t> px; bool ok() const { return w > 0; } };
+struct Gray { int w = 0, h = 0; std::vector<uint8_t> px, bgr; bool ok() const { return w > 0; } };   // px: gray, bgr: interleaved B,G,R
 
 static bool read_file(const std::string& p, std::vector<uint8_t>& out) {
     std::ifstream f(p, std::ios::binary);
@@ -49,6 +53,8 @@ static Gray read_pgm(const std::vector<uint8_t>& d) {
     i++;                                            // single whitespace after maxval
     if (n < 3 || vals[2] != 255 || d.size() < i + (size_t)vals[0] * vals[1]) return g;
     g.w = vals[0]; g.h = vals[1]; g.px.assign(d.begin() + i, d.begin() + i + (size_t)g.w * g.h);
+    g.bgr.resize(g.px.size() * 3);
+    for (size_t k = 0; k < g.px.size(); k++) g.bgr[3 * k] = g.bgr[3 * k + 1] = g.bgr[3 * k + 2] = g.px[k];   // cv::imread replicates gray files
     return g;
 }
 
@@ -85,10 +91,12 @@ static Gray read_png(const std::vector<uint8_t>& d) {
             cur[x] = (uint8_t)v;
         }
     }
-    g.w = w; g.h = h; g.px.resize((size_t)w * h);
+    g.w = w; g.h = h; g.px.resize((size_t)w * h); g.bgr.resize((size_t)w * h * 3);
     for (size_t i = 0; i < (size_t)w * h; i++) {
-        if (ch <= 2) g.px[i] = img[i * ch];
-        else { int R = img[i * ch], G = img[i * ch + 1], B = img[i * ch + 2]; g.px[i] = (uint8_t)((B * 1868 + G * 9617 + R * 4899 + 8192) >> 14); }   // BGR2GRAY
+        int R, G, B;
+        if (ch <= 2) { R = G = B = img[i * ch]; g.px[i] = (uint8_t)R; }
+        else { R = img[i * ch]; G = img[i * ch + 1]; B = img[i * ch + 2]; g.px[i] = (uint8_t)((B * 1868 + G * 9617 + R * 4899 + 8192) >> 14); }   // BGR2GRAY
+        g.bgr[3 * i] = (uint8_t)B; g.bgr[3 * i + 1] = (uint8_t)G; g.bgr[3 * i + 2] = (uint8_t)R;        // cv::imread: BGR, gray files replicated
     }
     return g;
 }
@@ -128,12 +136,15 @@ static void matmul4(const double* A, const double* B, double* C) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s <N_FRAMES> <folder> [--calib file.yaml] [--out result.csv] [--device d]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s <N_FRAMES> <folder> [--calib file.yaml] [--out result.csv] [--device d] [--gray 1] [--identity-start 1]\n", argv[0]); return 2; }
     const int N_FRAMES = std::atoi(argv[1]);
     const std::string folder = argv[2];
     std::string calib, out = folder + "/result.csv";
+    bool gray = false, identity_start = false;
     for (int i = 3; i + 1 < argc; i += 2) {
-        if (!strcmp(argv[i], "--calib")) calib = argv[i + 1];
+        if (!strcmp(argv[i], "--gray")) gray = std::atoi(argv[i + 1]) != 0;
+        else if (!strcmp(argv[i], "--identity-start")) identity_start = std::atoi(argv[i + 1]) != 0;
+        else if (!strcmp(argv[i], "--calib")) calib = argv[i + 1];
         else if (!strcmp(argv[i], "--out")) out = argv[i + 1];
         else if (!strcmp(argv[i], "--device")) default_device() = std::atoi(argv[i + 1]);
     }
@@ -153,6 +164,7 @@ int main(int argc, char** argv) {
         vo.initalize_projection_matricies(Pl, Pr);
         const double theta = (26.0 / 360) * 2 * M_PI;                                                    // main.cpp:368-373
         double pose[16] = {1, 0, 0, 0, 0, cos(theta), sin(theta), 0, 0, -sin(theta), cos(theta), 0, 0, 0, 0, 1};
+        if (identity_start) { const double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; memcpy(pose, I, sizeof(I)); }
         int done = 0;
         for (int i = 0; i < N_FRAMES; i++) {
             char name[64]; std::snprintf(name, sizeof(name), "/frame%06d", i);
@@ -164,7 +176,8 @@ int main(int argc, char** argv) {
                 std::getline(gt, xs, ','); std::getline(gt, ys, ','); std::getline(gt, dxs, ','); std::getline(gt, dys, ',');
                 gtx = atof(xs.c_str()); gty = atof(ys.c_str());
             }
-            auto o = vo.stereo_callback(Image(l.px.data(), l.h, l.w), Image(r.px.data(), r.h, r.w));
+            auto o = gray ? vo.stereo_callback(Image(l.px.data(), l.h, l.w), Image(r.px.data(), r.h, r.w))
+                          : vo.stereo_callback(Image(l.bgr.data(), l.h, l.w, 0, 3), Image(r.bgr.data(), r.h, r.w, 0, 3));
             matmul4(pose, o.second.data(), pose);                                                         // applied even when !ok (main.cpp:394-396)
             char row[256];
             std::snprintf(row, sizeof(row), "%.9g,%.9g,%.9g,%.9g,%.9g\n", pose[3], pose[7], pose[11], gtx, gty);
