@@ -16,13 +16,17 @@
  * function cites the reference call site it stands in for.
  *
  * Parity pin status (see DESIGN.md "Oracle"):
+ *   - END TO END, against output the reference itself recorded: fed the BGR frames of the reference's run1/ data set the
+ *     way its CLI feeds them (orc_vo_stereo_callback_cn, cn = 3), the whole pipeline reproduces run1/result.csv — the
+ *     6 significant digits the file holds for the first 13 frames, 2.1 cm RMSE over all 128 (tests/test_run1_color.py).
  *   - Bucket / FeatureSet logic, findClosePoints: pinned by the reference's own known-answer
  *     tests (src/main.cpp:50-78, 102-172), restated in tests/test_oracle_kat.py.
  *   - FAST-9/16 + NMS: pinned by test_featureset (src/main.cpp:102-127): 11 features, strength<=128.
  *   - pyramid + LK + circular mask: pinned by test_circularMatching (src/main.cpp:174-209): 121/121.
  *   - RANSAC-PnP + LM refine: pinned by test_cameraToWorld (src/main.cpp:211-264): R,t to 1e-8/1e-6.
  *   - Bit-level equality with OpenCV for LK / PnP / triangulation: PARITY UNPINNED (no OpenCV
- *     here, the reference binary cannot run, and no reference test covers triangulatePoints).
+ *     here, the reference binary cannot run, and no reference test covers triangulatePoints);
+ *     the recording above bounds the accumulated difference at 1e-6 m per frame.
  *
  * Deliberate, documented deviations from OpenCV numerics (all inside the pose tolerance):
  *   D1. LK accumulates A11,A12,A22,b1,b2 as exact int64 sums and converts to float once
