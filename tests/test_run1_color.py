@@ -152,3 +152,22 @@ def test_cli_reproduces_the_reference_result_csv(tmp_path):
     rows = evaluate.read_result_csv(folder / "result.csv")
     assert rows.shape == (16, 5)
     check_against_recording(rows[:, :3], recorded())
+
+
+@pytest.mark.gpu
+def test_bgr_batch_of_two_equals_two_single_runs():
+    """Two colour sequences in one context (different frames) give exactly what two single-sequence contexts give."""
+    from stereo_visual_odometry_amd import api
+    left, right = fixture_frames()
+    P = syn.projection_matrices(syn.RUN1)
+    cfg = api.default_config(); cfg.channels = 3
+    b = api.BatchVisualOdometry(512, 288, 2, cfg); b.initalize_projection_matricies(*P)
+    singles = []
+    for off in (0, 6):
+        v = api.VisualOdometry(cfg=api.default_config()); v.initalize_projection_matricies(*P); singles.append((v, off))
+    for k in range(8):
+        ok, T = b.stereo_callback_batch([left[k], left[k + 6]], [right[k], right[k + 6]])
+        for i, (v, off) in enumerate(singles):
+            ok1, T1 = v.stereo_callback(left[k + off], right[k + off])
+            assert bool(ok[i]) == ok1 and np.array_equal(T[i], T1), (k, i)
+            assert b.stats[i].as_dict() == v.stats.as_dict(), (k, i)
