@@ -171,3 +171,32 @@ def test_bgr_batch_of_two_equals_two_single_runs():
             ok1, T1 = v.stereo_callback(left[k + off], right[k + off])
             assert bool(ok[i]) == ok1 and np.array_equal(T[i], T1), (k, i)
             assert b.stats[i].as_dict() == v.stats.as_dict(), (k, i)
+
+
+@pytest.mark.gpu
+def test_bgr_device_images_async_with_padded_rows():
+    """Colour frames resident on the device (padded row stride), submitted asynchronously, give the poses of the host path."""
+    import torch
+    from stereo_visual_odometry_amd import api
+    left, right = fixture_frames()
+    P = syn.projection_matrices(syn.RUN1)
+    n, H, W, pad = 6, 288, 512, 64
+    stride = 3 * W + pad
+    def padded(frames):
+        a = np.zeros((n, H, stride), np.uint8)
+        a[:, :, :3 * W] = np.stack(frames[:n]).reshape(n, H, 3 * W)
+        a[:, :, 3 * W:] = 0xAB                                    # garbage in the padding must not matter
+        return torch.from_numpy(a).cuda()
+    L, R = padded(left), padded(right)
+    cfg = api.default_config(); cfg.channels = 3
+    b = api.BatchVisualOdometry(W, H, 1, cfg); b.initalize_projection_matricies(*P)
+    torch.cuda.synchronize()
+    for k in range(n):
+        b.submit_device([L.data_ptr() + k * H * stride], [R.data_ptr() + k * H * stride], stride)
+    got = [b.collect() for _ in range(n)]
+    v = api.VisualOdometry(cfg=api.default_config()); v.initalize_projection_matricies(*P)
+    for k in range(n):
+        ok1, T1 = v.stereo_callback(left[k], right[k])
+        assert bool(got[k][0][0]) == ok1 and np.array_equal(got[k][1][0], T1), k
+    with pytest.raises(api._lib.SvoError):                        # a stride shorter than a BGR row is refused
+        b.submit_device([L.data_ptr()], [R.data_ptr()], 3 * W - 1)
