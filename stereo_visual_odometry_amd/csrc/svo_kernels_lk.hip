@@ -562,27 +562,30 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mo
         if (idx >= n) continue;                                       // whole group idle (group-uniform)
         const size_t o = (size_t)seq * d.CAP + idx;
         const float2 p0 = d.feat_xy[s.feat_buf][o];                  // pointsLeftT0 = currentVOFeatures.points (vo.cpp:338)
-        // the four passes share ONE inlined copy of lk_pass (a loop, not four copies): 4x less code in the instruction cache
-        float2 p1 = p0, p2 = p0, p3 = p0, p4 = p0; int st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+        // the four passes share ONE inlined copy of lk_pass (a loop, not four copies): 4x less code in the instruction cache.
+        // Every pass's point is written out and folded into the masks as soon as it exists, so only the running point,
+        // the start point and two flags stay live across the passes (fewer registers held through lk_pass).
+        const bool writer = threadIdx.x % G == 0;
+        int allst = 1;
+        int inb = !((p0.x < 0) || (p0.y < 0) || (p0.y >= Hf) || (p0.x >= Wf));                        // vo.cpp:344-359, pointsLeftT0
         float2 cur = p0;
+        if (writer) d.pl0[o] = p0;
 #pragma unroll 1
         for (int pass = 0; pass < 4; pass++) {
             const uint8_t* A = pass == 0 ? L0 : pass == 1 ? L1 : pass == 2 ? R1 : R0;      // vo.cpp:203, 206, 209, 213
             const uint8_t* Bq = pass == 0 ? L1 : pass == 1 ? R1 : pass == 2 ? R0 : L0;
+            float2* out = pass == 0 ? d.pl1 : pass == 1 ? d.pr1 : pass == 2 ? d.pr0 : d.plc;
             float2 q; int st;
             lk_pass<W, G, CN>(d.geom, A, Bq, (size_t)d.geom.pyr_bytes, cur.x, cur.y, q.x, q.y, st, crit, sg);
-            if (pass == 0) { p1 = q; st0 = st; } else if (pass == 1) { p2 = q; st1 = st; } else if (pass == 2) { p3 = q; st2 = st; } else { p4 = q; st3 = st; }
+            allst &= (st != 0);
+            if (pass < 3) inb &= !((q.x < 0) || (q.y < 0) || (q.y >= Hf) || (q.x >= Wf));          // pl1, pr1, pr0 (not the returned point)
+            if (writer) out[o] = q;
             cur = q;
         }
-        if (threadIdx.x % G == 0) {
-            float ex = fabsf(p0.x - p4.x), ey = fabsf(p0.y - p4.y);
+        if (writer) {
+            float ex = fabsf(p0.x - cur.x), ey = fabsf(p0.y - cur.y);
             float off = (ex < ey) ? ey : ex;
-            int circ = st0 && st1 && st2 && st3 && !(off > thr);                        // vo.cpp:227-230
-            const float2 q[4] = {p0, p1, p3, p2};
-            int inb = 1;
-            for (int k = 0; k < 4; k++)
-                if ((q[k].x < 0) || (q[k].y < 0) || (q[k].y >= Hf) || (q[k].x >= Wf)) inb = 0;   // vo.cpp:344-359
-            d.pl0[o] = p0; d.pl1[o] = p1; d.pr1[o] = p2; d.pr0[o] = p3; d.plc[o] = p4;
+            int circ = allst && !(off > thr);                                               // vo.cpp:227-230
             d.okmask[o] = (uint8_t)(circ | (inb << 1));
         }
     }
