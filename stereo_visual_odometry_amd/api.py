@@ -342,10 +342,46 @@ class VisualOdometry(BatchVisualOdometry):
                 cfg.channels = 3
             super().__init__(L.shape[1], L.shape[0], 1, cfg, device)
             self._created = True
-            if self._P is not None:
-                super().initalize_projection_matricies(*self._P)
+            # like the reference, a first frame needs no projection matrices (vo.cpp:47-56 only caches); until
+            # initalize_projection_matricies is called they are all-zero, as the reference's empty Mats effectively are
+            super().initalize_projection_matricies(*(self._P if self._P is not None else (np.zeros(12, np.float32), np.zeros(12, np.float32))))
+        if L.ndim == 2:
+            self._last = (L.copy(), R.copy())         # the T0 side of a later circularMatching call (vo.h:239)
         T = np.zeros(16)
         st = SvoFrameStats()
         rc = check(lib.svo_process(self._h, ptr(L), ptr(R), L.strides[0], ptr(T), C.byref(st)))
         self.stats = st
         return bool(rc), T.reshape(4, 4)
+
+    def circularMatching(self, imgLeftT1, imgRightT1, pointsLeftT0, current_features):
+        """vo.h:374-379, vo.cpp:169-240.  Tracks pointsLeftT0 around T0-left -> T1-left -> T1-right -> T0-right -> T0-left against
+        the image pair of the previous stereo_callback / circularMatching, removes every point (and its feature, in place)
+        that lost an LK status or does not close the loop, makes the T1 pair the new "last" one.
+        Returns (pointsLeftT0, pointsRightT0, pointsLeftT1, pointsRightT1) — Python has no out-parameters."""
+        p0 = _pts(pointsLeftT0)
+        empty = np.zeros((0, 2), np.float32)
+        if len(p0) == 0:
+            return p0, empty, empty, empty                                                  # vo.cpp:179-181
+        if getattr(self, "_last", None) is None:
+            raise RuntimeError("circularMatching: no previous frame (call stereo_callback first)")
+        l1, r1 = u8img(imgLeftT1), u8img(imgRightT1)
+        cfg = self.cfg if getattr(self, "cfg", None) is not None else (self._args[0] or default_config())
+        pl1, pr1, pr0, _, ok = circularMatching(cfg, self._last[0], self._last[1], l1, r1, p0, self._args[1])
+        self._last = (l1.copy(), r1.copy())                                                 # vo.cpp:231-232
+        keep = ok.astype(bool)
+        deleteFeaturesWithFailureStatus(current_features, keep)                             # :233
+        return p0[keep], pr0[keep], pl1[keep], pr1[keep]                                    # :234-238
+
+    def matchingFeatures(self, imageLeftT0, imageRightT0, imageLeftT1, imageRightT1, currentVOFeatures):
+        """vo.h:354-362, vo.cpp:315-366 -> (pointsLeftT0, pointsRightT0, pointsLeftT1, pointsRightT1); the feature set is updated in place."""
+        currentVOFeatures.appendFeaturesFromImage(imageLeftT0, FAST_THRESHOLD)              # :325
+        if currentVOFeatures.size() < PRE_MATCHING_FEATURE_THRESHOLD:                       # :327-332
+            currentVOFeatures.appendFeaturesFromImage(imageLeftT0, FAST_THRESHOLD // 4)
+        self._last = (u8img(imageLeftT0).copy(), u8img(imageRightT0).copy())
+        pl0, pr0, pl1, pr1 = self.circularMatching(imageLeftT1, imageRightT1, currentVOFeatures.points.copy(), currentVOFeatures)
+        h, w = u8img(imageLeftT1).shape
+        inside = np.ones(len(pl0), bool)                                                    # :341-359
+        for q in (pl0, pl1, pr0, pr1):
+            inside &= ~((q[:, 0] < 0) | (q[:, 1] < 0) | (q[:, 1] >= h) | (q[:, 0] >= w))
+        deleteFeaturesWithFailureStatus(currentVOFeatures, inside)                          # :360-364
+        return pl0[inside], pr0[inside], pl1[inside], pr1[inside]

@@ -87,12 +87,62 @@ static void test_stereo_callback_shape() {                          // the callb
     (void)b;
 }
 
+static void test_circularMatching() {                                // main.cpp:174-209, member-function form
+    Img l0(600, 600), r0(600, 600), l1(600, 600), r1(600, 600);
+    for (int i = 0; i <= 10; i++) for (int j = 0; j <= 10; j++) {
+        addTriangle(l0, (j + 1) * 40, (i + 1) * 40, 8); addTriangle(l1, (j + 1) * 40 + 1, (i + 1) * 40, 8);
+        addTriangle(r0, (j + 1) * 40, (i + 1) * 40 + 1, 8); addTriangle(r1, (j + 1) * 40 + 1, (i + 1) * 40 + 1, 8);
+    }
+    VisualOdometry vo;
+    std::vector<Point2f> pl0, pr0, pl1, pr1;
+    vo.stereo_callback(l0.view(), r0.view());
+    FeatureSet fs;
+    fs.appendFeaturesFromImage(l0.view(), FAST_THRESHOLD);
+    vo.circularMatching(l1.view(), r1.view(), pl0, pr0, pl1, pr1, fs);          // boundary condition: no points, no crash
+    pl0.push_back(fs.points[0]);
+    vo.circularMatching(l1.view(), r1.view(), pl0, pr0, pl1, pr1, fs);          // one point against a larger feature set
+    // the run the reference asserts on; its second call above has made (l1, r1) the cached pair, so the loop is
+    // L1 -> L1 -> R1 -> R1 -> L1, exactly as in the reference's own test
+    FeatureSet fs2;
+    fs2.appendFeaturesFromImage(l0.view(), FAST_THRESHOLD);
+    pl0 = fs2.points;
+    vo.circularMatching(l1.view(), r1.view(), pl0, pr0, pl1, pr1, fs2);
+    const size_t n_points = fs2.points.size();
+    CHECK(pl0.size() == n_points && pl1.size() == n_points && pr0.size() == n_points && pr1.size() == n_points);
+    CHECK(n_points == 121);
+}
+
+static void test_matchingFeatures() {                                // vo.h:354-362: the pipeline stereo_callback runs, as a member call
+    Img l0(600, 600), r0(600, 600), l1(600, 600), r1(600, 600);
+    for (int i = 0; i <= 10; i++) for (int j = 0; j <= 10; j++) {
+        addTriangle(l0, (j + 1) * 40, (i + 1) * 40, 8); addTriangle(l1, (j + 1) * 40 + 1, (i + 1) * 40, 8);
+        addTriangle(r0, (j + 1) * 40, (i + 1) * 40 + 1, 8); addTriangle(r1, (j + 1) * 40 + 1, (i + 1) * 40 + 1, 8);
+    }
+    VisualOdometry vo;
+    FeatureSet fs;
+    std::vector<Point2f> pl0, pr0, pl1, pr1;
+    vo.matchingFeatures(l0.view(), r0.view(), l1.view(), r1.view(), fs, pl0, pr0, pl1, pr1);
+    CHECK(fs.points.size() == 121 && pl0.size() == 121 && pl1.size() == 121 && pr0.size() == 121 && pr1.size() == 121);
+    for (size_t i = 0; i < pl0.size(); i++) {                        // the scene moves by exactly (+1, 0) in the left view and the
+        CHECK(std::fabs(pl1[i].x - pl0[i].x - 1) < 0.05f && std::fabs(pl1[i].y - pl0[i].y) < 0.05f);   // right cameras see it one row lower
+        CHECK(std::fabs(pr0[i].y - pl0[i].y - 1) < 0.05f && std::fabs(pr1[i].x - pl0[i].x - 1) < 0.05f);
+    }
+    // and it is what stereo_callback computes internally on the same two frames
+    VisualOdometry vo2;
+    Mat34f Pl = {322.11376f, 0, 327.47336f, 0, 0, 322.11376f, 176.33722f, 0, 0, 0, 1, 0}; Mat34f Pr = Pl; Pr[3] = -22.5428f;
+    vo2.initalize_projection_matricies(Pl, Pr);
+    vo2.stereo_callback(l0.view(), r0.view()); vo2.stereo_callback(l1.view(), r1.view());
+    CHECK(vo2.stats.n_after_bounds == 121);
+}
+
 int main() {
     std::puts("TEST BUCKET"); test_bucket();
     std::puts("TEST FEATURE SET"); test_featureset();
     std::puts("TEST FIND UNMOVED POINTS"); test_findUnmovedPoints();
     std::puts("TEST CAMERA TO WORLD"); test_cameraToWorld();
     std::puts("TEST STEREO CALLBACK"); test_stereo_callback_shape();
+    std::puts("TEST CIRCULAR MATCHING"); test_circularMatching();
+    std::puts("TEST MATCHING FEATURES"); test_matchingFeatures();
     std::puts("ALL TESTS PASS");
     return 0;
 }
