@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--contexts", type=int, default=2, help="sequence groups per GPU, each on its own HIP stream (their kernels overlap)")
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic sequences rendered per rank")
     ap.add_argument("--frames", type=int, default=10, help="frames rendered per pool sequence (ping-pong replay)")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=120, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg5"],
                     help="BASELINE.json configs[1] (the metric's configuration, default) / configs[2] / configs[4]; the others are extra measurements")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
