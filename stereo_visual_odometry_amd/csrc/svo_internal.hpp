@@ -49,6 +49,7 @@ struct DevBuffers {
     Geometry geom;
     svo_config cfg;
     int bucket_h, bucket_w;
+    float lk_mineig_cut;                       // LK: numerators below this fail the minimum-eigenvalue test (see lk_mineig_cut())
     SeqState* st;                              // [B]
     uint8_t* pyr;                              // [B][3 slots][2 cams][CN planes][pyr_bytes]
     uint8_t* fastimg;                          // CN == 3 only: [B][3 slots][W*H] the first W bytes of every interleaved left row —
@@ -100,3 +101,4 @@ void launch_lk_single(const DevBuffers& d, int slotA, int camA, int slotB, int c
 void launch_find_close(int n, const float2* a, const float2* b, float thr, uint8_t* ok, hipStream_t s);
 bool lk_window_supported(int win);
 bool lk_window_supported_cn(int win, int cn);
+float lk_mineig_cut(int win, double min_eig_threshold);

@@ -24,6 +24,7 @@
 //     and every branch are wave-uniform.
 #include "svo_internal.hpp"
 #include <stdlib.h>
+#include <string.h>
 
 #define LK_WBITS 14
 // Newton-loop form per lanes-per-feature: 0 = epochs, 1 = flat
@@ -175,7 +176,7 @@ __device__ __forceinline__ void lk_weights(float a, float b, unsigned& w0, unsig
     w1 = pack_lo16((int)m10, (int)iw11);
 }
 
-struct LkCrit { int max_count; double eps2; double min_eig; };
+struct LkCrit { int max_count; double eps2; float mineig_cut; };
 template <int SPL> struct LkSegs { int row[SPL]; int xs[SPL]; bool on[SPL]; };   // the window segments a lane owns
 
 typedef short short2v __attribute__((ext_vector_type(2)));
@@ -351,8 +352,12 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         const bool narrow = As[0] < NARROW_LIMIT && As[2] < NARROW_LIMIT;
         const float A11 = As[0] * FLT_SCALE, A12 = As[1] * FLT_SCALE, A22 = As[2] * FLT_SCALE;
         float Dt = A11 * A22 - A12 * A12;
-        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * W * W);
-        if ((double)minEig < crit.min_eig || Dt < 1.1920928955078125e-07f) {
+        // lkpyramid.cpp: minEig = (A22 + A11 - sqrt(...)) / (2 * winSize.area());  if (minEig < minEigThreshold || D < FLT_EPSILON) skip.
+        // The f32 division and the f64 comparison are folded into one f32 comparison of the numerator against a cut-off the
+        // host found by bisection over the floats (lk_mineig_cut): division by a positive constant is monotone, so
+        // "(double)fl(num / den) < threshold"  <=>  "num < cut" exactly.
+        const float eig_num = A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12);
+        if (eig_num < crit.mineig_cut || Dt < 1.1920928955078125e-07f) {
             if (level == 0) status = 0;
             continue;
         }
@@ -413,7 +418,15 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             float bs[2];
             {
                 const int pb[2] = {pb1, pb2};
-                if (narrow) group_sums_to_float_narrow<G, 2>(pb, bs);
+                // narrow (int32 end to end) when the level's Cauchy-Schwarz bound allows it, or when this iteration's own
+                // partials are small: every lane |partial| < 2^25  =>  any sum over the <= 64 lanes of a group stays below 2^31
+                bool nar = narrow;
+                if (!nar) {
+                    const bool big = ((unsigned)(pb1 + (1 << 25)) | (unsigned)(pb2 + (1 << 25))) >= (1u << 26);
+                    const unsigned long long bigs = __builtin_amdgcn_ballot_w64(big);
+                    nar = G == 64 ? bigs == 0ull : ((bigs >> ((threadIdx.x / G) * G)) & ((G == 64 ? 0ull : (1ull << (G & 63))) - 1ull)) == 0ull;
+                }
+                if (nar) group_sums_to_float_narrow<G, 2>(pb, bs);
                 else group_sums_to_float<G, 2, PRE>(pb, bs);
             }
             const float b1 = bs[0] * FLT_SCALE, b2 = bs[1] * FLT_SCALE;
@@ -490,11 +503,11 @@ __device__ __forceinline__ void lk_segments(LkSegs<LkLayout<W, G>::SPL>& sg) {
     }
 }
 
-__device__ __forceinline__ LkCrit make_crit(const svo_config& c) {
+__device__ __forceinline__ LkCrit make_crit(const svo_config& c, float mineig_cut) {
     LkCrit k;
     int mc = c.lk_max_count; mc = mc < 0 ? 0 : (mc > 100 ? 100 : mc);       // TermCriteria normalisation (lkpyramid.cpp)
     double e = c.lk_epsilon; e = e < 0. ? 0. : (e > 10. ? 10. : e);
-    k.max_count = mc; k.eps2 = e * e; k.min_eig = c.optical_flow_min_eig_threshold;
+    k.max_count = mc; k.eps2 = e * e; k.mineig_cut = mineig_cut;
     return k;
 }
 
@@ -541,7 +554,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK_MIN_WAVES
     const uint8_t* R0 = d.pyr + pyr_index(d, seq, s.slot_pyr_t0, 1);
     const uint8_t* L1 = d.pyr + pyr_index(d, seq, s.slot_t1, 0);
     const uint8_t* R1 = d.pyr + pyr_index(d, seq, s.slot_t1, 1);
-    const LkCrit crit = make_crit(d.cfg);
+    const LkCrit crit = make_crit(d.cfg, d.lk_mineig_cut);
     const float thr = (float)d.cfg.circular_matching_success_threshold;                // findClosePoints takes a float32 (vo.h:432)
     const float Wf = (float)d.geom.W, Hf = (float)d.geom.H;
     LkSegs<LkLayout<W, G>::SPL> sg;
@@ -601,7 +614,7 @@ __global__ __launch_bounds__(64) void k_lk_single(DevBuffers d, int slotA, int c
     constexpr int FPW = 64 / G;
     const uint8_t* A = d.pyr + pyr_index(d, 0, slotA, camA);
     const uint8_t* Bp = d.pyr + pyr_index(d, 0, slotB, camB);
-    const LkCrit crit = make_crit(d.cfg);
+    const LkCrit crit = make_crit(d.cfg, d.lk_mineig_cut);
     LkSegs<LkLayout<W, G>::SPL> sg;
     lk_segments<W, G>(sg);
     const int slot = threadIdx.x / G;
@@ -624,6 +637,19 @@ static int lk_xcd_mapping() { static int v = -1; if (v < 0) { const char* e = ge
 // 3-channel (BGR) instantiations: one per window, at the window's default lanes-per-feature (w = 31 would need 48 pixels of
 // template and search window per lane, more registers than a wave has)
 #define LK_FOR_EACH_WINDOW_CN3(X) X(7, 16) X(10, 16) X(15, 32) X(21, 64)
+
+// Smallest float x with (double)(float)(x / (2 w^2)) >= threshold — found by bisection over the floats in their numeric order
+// (IEEE f32 division on the host, the same operation the kernel would do).  +inf if no finite float qualifies.
+float lk_mineig_cut(int win, double threshold) {
+    const float den = (float)(2 * win * win);
+    auto key_to_float = [](uint32_t k) { uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float f; memcpy(&f, &b, 4); return f; };   // increasing in k
+    auto ok = [&](uint32_t k) { const float q = key_to_float(k) / den; return (double)q >= threshold; };
+    uint32_t lo = 0x00800000u, hi = 0xFF7FFFFFu;          // keys of -FLT_MAX .. +FLT_MAX
+    if (!ok(hi)) return __builtin_inff();
+    if (ok(lo)) return key_to_float(lo);
+    while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (ok(mid)) hi = mid; else lo = mid; }
+    return key_to_float(hi);
+}
 
 bool lk_window_supported(int win) {
 #define CHK(Wn, Gn) if (win == Wn) return true;
