@@ -346,7 +346,16 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             }
         }
         float As[3];
-        { const int pa[3] = {pA11, pA12, pA22}; group_sums_to_float<G, 3, PRE>(pa, As); }
+        {
+            const int pa[3] = {pA11, pA12, pA22};
+            // pA11, pA22 >= 0 and |pA12| <= (pA11 + pA22) / 2 per lane (|ab| <= (a^2 + b^2) / 2 term by term), so one unsigned
+            // compare bounds all three partials: below 2^25 per lane the group sums stay inside int32 -> narrow reduction
+            const bool big = ((unsigned)pA11 | (unsigned)pA22) >= (1u << 25);
+            const unsigned long long bigs = __builtin_amdgcn_ballot_w64(big);
+            const bool nar = G == 64 ? bigs == 0ull : ((bigs >> ((threadIdx.x / G) * G)) & ((G == 64 ? 0ull : (1ull << (G & 63))) - 1ull)) == 0ull;
+            if (nar) group_sums_to_float_narrow<G, 3>(pa, As);
+            else group_sums_to_float<G, 3, PRE>(pa, As);
+        }
         // |sum diff*Ix| <= 8160 * sqrt(CN W^2 * sum Ix^2) (Cauchy-Schwarz): below 2^31 when sum Ix^2 < 2^62 / (8160^2 CN W^2); 5 % margin
         // covers the float rounding of As.  Then the mismatch sums never leave int32 and take the narrow reduction.
         const bool narrow = As[0] < NARROW_LIMIT && As[2] < NARROW_LIMIT;
@@ -457,7 +466,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 const float fx0 = (float)inx, fy0 = (float)iny;
                 for (;;) {
                     if (newton_step(fx0, fy0)) { stop = true; break; }
-                    if ((int)floorf(nx) != inx || (int)floorf(ny) != iny) break;       // integer origin moved: new epoch
+                    if (floorf(nx) != fx0 || floorf(ny) != fy0) break;                 // integer origin moved: new epoch (exact: |n| < 2^24)
                 }
             }
         } else {
