@@ -288,12 +288,21 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                         T0[c] = __builtin_bit_cast(ushort2v, hi_lo16(__builtin_bit_cast(unsigned, T0[c - 1]), __builtin_bit_cast(unsigned, T0[c + 1])));
                         T1[c] = __builtin_bit_cast(short2v, hi_lo16(__builtin_bit_cast(unsigned, T1[c - 1]), __builtin_bit_cast(unsigned, T1[c + 1])));
                     }
+                    // horizontal passes: evaluated for the even pixels; an odd pixel's pair is again (upper half of its left
+                    // neighbour's pair, lower half of its right neighbour's) — unless it is the last pixel, which is computed directly
 #pragma unroll
                     for (int x = 0; x < PPL; x++) {
+                        if ((x & 1) && x + 1 < PPL) continue;
                         DXp[yy][x] = __builtin_bit_cast(unsigned, (ushort2v)(T0[x + 2] - T0[x]));
                         DYp[yy][x] = __builtin_bit_cast(unsigned, (short2v)((T1[x] + T1[x + 2]) * (short)3 + T1[x + 1] * (short)10));
-                        Ip[yy][x] = Q[yy + 1][x + 1];
                     }
+#pragma unroll
+                    for (int x = 1; x + 1 < PPL; x += 2) {
+                        DXp[yy][x] = hi_lo16(DXp[yy][x - 1], DXp[yy][x + 1]);
+                        DYp[yy][x] = hi_lo16(DYp[yy][x - 1], DYp[yy][x + 1]);
+                    }
+#pragma unroll
+                    for (int x = 0; x < PPL; x++) Ip[yy][x] = Q[yy + 1][x + 1];
                 }
             } else {
                 int sv[4][NS];
