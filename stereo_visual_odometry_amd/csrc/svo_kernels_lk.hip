@@ -351,7 +351,8 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             for (int q = 0; q < NPR; q++) {
                 Ixp[kk][q] = (2 * q + 1 < PPL) ? pack_lo16(ixv[2 * q], ixv[2 * q + 1]) : ((unsigned)ixv[2 * q] & 0xFFFFu);
                 Iyp[kk][q] = (2 * q + 1 < PPL) ? pack_lo16(iyv[2 * q], iyv[2 * q + 1]) : ((unsigned)iyv[2 * q] & 0xFFFFu);
-                pA11 = dot2(Ixp[kk][q], Ixp[kk][q], pA11); pA12 = dot2(Ixp[kk][q], Iyp[kk][q], pA12); pA22 = dot2(Iyp[kk][q], Iyp[kk][q], pA22);
+                if (kk == 0 && q == 0) { pA11 = dot2_keep(Ixp[0][0], Ixp[0][0], 0); pA12 = dot2_keep(Ixp[0][0], Iyp[0][0], 0); pA22 = dot2_keep(Iyp[0][0], Iyp[0][0], 0); }
+                else { pA11 = dot2(Ixp[kk][q], Ixp[kk][q], pA11); pA12 = dot2(Ixp[kk][q], Iyp[kk][q], pA12); pA22 = dot2(Iyp[kk][q], Iyp[kk][q], pA22); }
             }
         }
         float As[3];
@@ -430,7 +431,8 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 for (int q = 0; q < NPR; q++) {
                     // masked pixels (and the unpaired upper half) have Ix = Iy = 0: whatever mismatch they see contributes an exact zero
                     const unsigned dp = (2 * q + 1 < PPL) ? pack_lo16(dv[2 * q], dv[2 * q + 1]) : (unsigned)dv[2 * q];
-                    pb1 = dot2(dp, Ixp[kk][q], pb1); pb2 = dot2(dp, Iyp[kk][q], pb2);
+                    if (kk == 0 && q == 0) { pb1 = dot2_keep(dp, Ixp[0][0], 0); pb2 = dot2_keep(dp, Iyp[0][0], 0); }   // no accumulator to clear first
+                    else { pb1 = dot2(dp, Ixp[kk][q], pb1); pb2 = dot2(dp, Iyp[kk][q], pb2); }
                 }
             }
             float bs[2];
