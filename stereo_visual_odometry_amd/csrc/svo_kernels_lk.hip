@@ -266,73 +266,70 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             const uint8_t* __restrict__ Ap = A + (size_t)(kk / SPL) * pstride;       // this colour plane
             const int row = sg.row[k], xs = sg.xs[k];
             unsigned Ip[2][PPL], DXp[2][PPL], DYp[2][PPL];             // [row 0/1 of the bilinear][pixel]: packed pairs
+            // source pairs of the four rows: interior windows take unaligned dword loads; windows over the image border gather
+            // their bytes through REFLECT_101 (the border of the pyramid level) — everything after that is shared
+            unsigned Q[4][NS - 1];
             if (interior) {
-                unsigned Q[4][NS - 1];
                 const uint8_t* p = Ap + (size_t)(ipy - 1 + row) * L.w + (ipx - 1 + xs);
 #pragma unroll
                 for (int r = 0; r < 4; r++) load_pairs<NS>(p + (size_t)r * L.w, Q[r]);
-#pragma unroll
-                for (int yy = 0; yy < 2; yy++) {
-                    // the vertical passes are evaluated on the EVEN pairs (columns 2i, 2i+1); an odd pair is the upper half of
-                    // its left neighbour next to the lower half of its right one — one v_perm instead of recomputing both columns
-                    ushort2v T0[NS - 1]; short2v T1[NS - 1];
-#pragma unroll
-                    for (int c = 0; c < NS - 1; c++) {
-                        if ((c & 1) && c + 1 < NS - 1) continue;
-                        const ushort2v q0 = __builtin_bit_cast(ushort2v, Q[yy][c]), q1 = __builtin_bit_cast(ushort2v, Q[yy + 1][c]), q2 = __builtin_bit_cast(ushort2v, Q[yy + 2][c]);
-                        T0[c] = (q0 + q2) * (unsigned short)3 + q1 * (unsigned short)10;
-                        T1[c] = __builtin_bit_cast(short2v, (ushort2v)(q2 - q0));
-                    }
-#pragma unroll
-                    for (int c = 1; c + 1 < NS - 1; c += 2) {
-                        T0[c] = __builtin_bit_cast(ushort2v, hi_lo16(__builtin_bit_cast(unsigned, T0[c - 1]), __builtin_bit_cast(unsigned, T0[c + 1])));
-                        T1[c] = __builtin_bit_cast(short2v, hi_lo16(__builtin_bit_cast(unsigned, T1[c - 1]), __builtin_bit_cast(unsigned, T1[c + 1])));
-                    }
-                    // horizontal passes: evaluated for the even pixels; an odd pixel's pair is again (upper half of its left
-                    // neighbour's pair, lower half of its right neighbour's) — unless it is the last pixel, which is computed directly
-#pragma unroll
-                    for (int x = 0; x < PPL; x++) {
-                        if ((x & 1) && x + 1 < PPL) continue;
-                        DXp[yy][x] = __builtin_bit_cast(unsigned, (ushort2v)(T0[x + 2] - T0[x]));
-                        DYp[yy][x] = __builtin_bit_cast(unsigned, (short2v)((T1[x] + T1[x + 2]) * (short)3 + T1[x + 1] * (short)10));
-                    }
-#pragma unroll
-                    for (int x = 1; x + 1 < PPL; x += 2) {
-                        DXp[yy][x] = hi_lo16(DXp[yy][x - 1], DXp[yy][x + 1]);
-                        DYp[yy][x] = hi_lo16(DYp[yy][x - 1], DYp[yy][x + 1]);
-                    }
-#pragma unroll
-                    for (int x = 0; x < PPL; x++) Ip[yy][x] = Q[yy + 1][x + 1];
-                }
             } else {
-                int sv[4][NS];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const uint8_t* rp = Ap + (size_t)reflect101(ipy - 1 + row + r, L.h) * L.w;
+                    int prev = rp[reflect101(ipx - 1 + xs, L.w)];
 #pragma unroll
-                    for (int c = 0; c < NS; c++) sv[r][c] = rp[reflect101(ipx - 1 + xs + c, L.w)];
-                }
-                int dxv[2][NB], dyv[2][NB];
-#pragma unroll
-                for (int yy = 0; yy < 2; yy++)
-#pragma unroll
-                    for (int xx = 0; xx < NB; xx++) {
-                        int t0m = 3 * (sv[yy][xx] + sv[yy + 2][xx]) + 10 * sv[yy + 1][xx];
-                        int t0p = 3 * (sv[yy][xx + 2] + sv[yy + 2][xx + 2]) + 10 * sv[yy + 1][xx + 2];
-                        int t1m = sv[yy + 2][xx] - sv[yy][xx], t1c = sv[yy + 2][xx + 1] - sv[yy][xx + 1], t1p = sv[yy + 2][xx + 2] - sv[yy][xx + 2];
-                        int da = t0p - t0m, db = 3 * (t1m + t1p) + 10 * t1c;
-                        int gx = ipx + xs + xx, gy = ipy + row + yy;
-                        if (gx < 0 || gx >= L.w || gy < 0 || gy >= L.h) { da = 0; db = 0; }     // derivBorder = CONSTANT 0
-                        dxv[yy][xx] = da; dyv[yy][xx] = db;
+                    for (int c = 0; c < NS - 1; c++) {
+                        const int nxt = rp[reflect101(ipx + xs + c, L.w)];
+                        Q[r][c] = pack16(prev, nxt);
+                        prev = nxt;
                     }
+                }
+            }
 #pragma unroll
-                for (int yy = 0; yy < 2; yy++)
+            for (int yy = 0; yy < 2; yy++) {
+                // the vertical passes are evaluated on the EVEN pairs (columns 2i, 2i+1); an odd pair is the upper half of
+                // its left neighbour next to the lower half of its right one — one v_perm instead of recomputing both columns
+                ushort2v T0[NS - 1]; short2v T1[NS - 1];
+#pragma unroll
+                for (int c = 0; c < NS - 1; c++) {
+                    if ((c & 1) && c + 1 < NS - 1) continue;
+                    const ushort2v q0 = __builtin_bit_cast(ushort2v, Q[yy][c]), q1 = __builtin_bit_cast(ushort2v, Q[yy + 1][c]), q2 = __builtin_bit_cast(ushort2v, Q[yy + 2][c]);
+                    T0[c] = (q0 + q2) * (unsigned short)3 + q1 * (unsigned short)10;
+                    T1[c] = __builtin_bit_cast(short2v, (ushort2v)(q2 - q0));
+                }
+#pragma unroll
+                for (int c = 1; c + 1 < NS - 1; c += 2) {
+                    T0[c] = __builtin_bit_cast(ushort2v, hi_lo16(__builtin_bit_cast(unsigned, T0[c - 1]), __builtin_bit_cast(unsigned, T0[c + 1])));
+                    T1[c] = __builtin_bit_cast(short2v, hi_lo16(__builtin_bit_cast(unsigned, T1[c - 1]), __builtin_bit_cast(unsigned, T1[c + 1])));
+                }
+                // horizontal passes: evaluated for the even pixels; an odd pixel's pair is again (upper half of its left
+                // neighbour's pair, lower half of its right neighbour's) — unless it is the last pixel, which is computed directly
+#pragma unroll
+                for (int x = 0; x < PPL; x++) {
+                    if ((x & 1) && x + 1 < PPL) continue;
+                    DXp[yy][x] = __builtin_bit_cast(unsigned, (ushort2v)(T0[x + 2] - T0[x]));
+                    DYp[yy][x] = __builtin_bit_cast(unsigned, (short2v)((T1[x] + T1[x + 2]) * (short)3 + T1[x + 1] * (short)10));
+                }
+#pragma unroll
+                for (int x = 1; x + 1 < PPL; x += 2) {
+                    DXp[yy][x] = hi_lo16(DXp[yy][x - 1], DXp[yy][x + 1]);
+                    DYp[yy][x] = hi_lo16(DYp[yy][x - 1], DYp[yy][x + 1]);
+                }
+#pragma unroll
+                for (int x = 0; x < PPL; x++) Ip[yy][x] = Q[yy + 1][x + 1];
+                if (!interior) {
+                    // the derivative image has a CONSTANT 0 border (buildOpticalFlowPyramid: derivBorder): samples outside the
+                    // level are zero, not derivatives of the reflected image
+                    const int gy = ipy + row + yy;
+                    const bool rowin = gy >= 0 && gy < L.h;
 #pragma unroll
                     for (int x = 0; x < PPL; x++) {
-                        DXp[yy][x] = pack16(dxv[yy][x], dxv[yy][x + 1]);
-                        DYp[yy][x] = pack16(dyv[yy][x], dyv[yy][x + 1]);
-                        Ip[yy][x] = pack16(sv[yy + 1][x + 1], sv[yy + 1][x + 2]);
+                        const int gx = ipx + xs + x;
+                        const unsigned m = ((rowin && gx >= 0 && gx < L.w) ? 0x0000FFFFu : 0u) | ((rowin && gx + 1 >= 0 && gx + 1 < L.w) ? 0xFFFF0000u : 0u);
+                        DXp[yy][x] &= m; DYp[yy][x] &= m;
                     }
+                }
             }
             // patch samples (kept in registers for the Newton loop) + covariance partials.  Segments / pixels outside
             // the window get zero derivative weights: their Ix = Iy = 0, so they contribute exact zeros everywhere.
@@ -550,8 +547,9 @@ __device__ __forceinline__ LkCrit make_crit(const svo_config& c, float mineig_cu
 #define LK_MAP_AFFINE 1
 #define LK_MAP_INTERLEAVED 2
 // Registers: the headline instantiation (w = 21, one feature per wave, single channel) is asked to fit five waves per SIMD;
-// it does so in 93 VGPRs without scratch.  The others keep the compiler's default (they would spill).
-#define LK_MIN_WAVES(W, G, CN) (((W) == 21 && (G) == 64 && (CN) == 1) ? 5 : 1)
+// it does so in 91 VGPRs without scratch; w = 31 fits three (150 VGPRs).  The others keep the compiler's default (any
+// further wave would spill).
+#define LK_MIN_WAVES(W, G, CN) (((W) == 21 && (G) == 64 && (CN) == 1) ? 5 : ((W) == 31 && (G) == 64 && (CN) == 1) ? 3 : 1)
 template <int W, int G, int CN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK_MIN_WAVES(W, G, CN), 8))) void k_lk_chain(DevBuffers d, int slots, int mode, int chunk) {
     constexpr int FPW = 64 / G;                                       // features per wave (= per block)
