@@ -398,15 +398,17 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
 #pragma unroll
                 for (int kk = 0; kk < KS; kk++) {
                     const int k = kk % SPL;
-                    int jb[2][NB];
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
                         const uint8_t* rp = Bm + (size_t)(kk / SPL) * pstride + (size_t)reflect101(iny + sg.row[k] + r, L.h) * L.w;
+                        int prev = rp[reflect101(inx + sg.xs[k], L.w)];
 #pragma unroll
-                        for (int c = 0; c < NB; c++) jb[r][c] = rp[reflect101(inx + sg.xs[k] + c, L.w)];
+                        for (int c = 0; c < PPL; c++) {
+                            const int nxt = rp[reflect101(inx + sg.xs[k] + c + 1, L.w)];
+                            (r ? P1 : P0)[kk][c] = pack16(prev, nxt);
+                            prev = nxt;
+                        }
                     }
-#pragma unroll
-                    for (int c = 0; c < PPL; c++) { P0[kk][c] = pack16(jb[0][c], jb[0][c + 1]); P1[kk][c] = pack16(jb[1][c], jb[1][c + 1]); }
                 }
             }
         };
