@@ -151,6 +151,8 @@ __device__ __forceinline__ void group_sums_to_float_narrow(const int (&partial)[
 
 // (upper half of a, lower half of b) as one packed pair
 __device__ __forceinline__ unsigned hi_lo16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040302u); }
+// upper halves of two registers -> one packed pair
+__device__ __forceinline__ unsigned pack_hi16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x07060302u); }
 // low halves of two registers -> one packed pair (one v_perm_b32)
 __device__ __forceinline__ unsigned pack_lo16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
 
@@ -250,7 +252,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         // and the Scharr derivatives are computed with packed 16-bit math directly on those pairs:
         //   t0(c) = 3*(s[y-1][c] + s[y+1][c]) + 10*s[y][c]      t1(c) = s[y+1][c] - s[y-1][c]
         //   dx(c) = t0(c+1) - t0(c-1)                            dy(c) = 3*(t1(c-1) + t1(c+1)) + 10*t1(c)
-        // (all intermediates fit 16 bits: |t0| <= 4080, |dx|, |dy| <= 4080).
+        // carried at 4 x their value (coefficients 12 / 40; everything still fits 16 bits: 4 |t0|, 4 |dx|, 4 |dy| <= 16320).
         // Kept for the Newton loop, per owned pixel: Kr = 2^(WBITS-6) - (I << (WBITS-5)), the seed of the bilinear dot product
         // of the search image, so that (seed + J-dot) >> (WBITS-5) IS the mismatch J - I (the subtrahend is a multiple of the
         // shift unit, so folding it in is exact); and the derivatives as packed signed 16-bit pairs of adjacent pixels, the
@@ -295,7 +297,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 for (int c = 0; c < NS - 1; c++) {
                     if ((c & 1) && c + 1 < NS - 1) continue;
                     const ushort2v q0 = __builtin_bit_cast(ushort2v, Q[yy][c]), q1 = __builtin_bit_cast(ushort2v, Q[yy + 1][c]), q2 = __builtin_bit_cast(ushort2v, Q[yy + 2][c]);
-                    T0[c] = (q0 + q2) * (unsigned short)3 + q1 * (unsigned short)10;
+                    T0[c] = (q0 + q2) * (unsigned short)12 + q1 * (unsigned short)40;           // 4 x Scharr smoothing (<= 16320)
                     T1[c] = __builtin_bit_cast(short2v, (ushort2v)(q2 - q0));
                 }
 #pragma unroll
@@ -309,7 +311,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 for (int x = 0; x < PPL; x++) {
                     if ((x & 1) && x + 1 < PPL) continue;
                     DXp[yy][x] = __builtin_bit_cast(unsigned, (ushort2v)(T0[x + 2] - T0[x]));
-                    DYp[yy][x] = __builtin_bit_cast(unsigned, (short2v)((T1[x] + T1[x + 2]) * (short)3 + T1[x + 1] * (short)10));
+                    DYp[yy][x] = __builtin_bit_cast(unsigned, (short2v)((T1[x] + T1[x + 2]) * (short)12 + T1[x + 1] * (short)40));
                 }
 #pragma unroll
                 for (int x = 1; x + 1 < PPL; x += 2) {
@@ -340,14 +342,16 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 const bool on = (EXT == W) || (xs + j < W);
                 const int iacc = dot2(Ip[1][j], w1, dot2(Ip[0][j], w0, 1 << (LK_WBITS - 6)));          // I = iacc >> (WBITS-5)
                 Kr[kk][j] = (1 << (LK_WBITS - 6)) - (iacc & ~((1 << (LK_WBITS - 5)) - 1));
-                const int ixval = dot2(DXp[1][j], wd1, dot2(DXp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
-                const int iyval = dot2(DYp[1][j], wd1, dot2(DYp[0][j], wd0, 1 << (LK_WBITS - 1))) >> LK_WBITS;
-                ixv[j] = on ? ixval : 0; iyv[j] = on ? iyval : 0;
+                // the derivative pairs carry 4 x the Scharr value (coefficients 12 / 40 above, still inside 16 bits), so the
+                // 14-bit descale of the bilinear sum becomes "take the upper half": (4 S + 2^15) >> 16 == (S + 2^13) >> 14
+                const int ixacc = dot2(DXp[1][j], wd1, dot2(DXp[0][j], wd0, 1 << (LK_WBITS + 1)));
+                const int iyacc = dot2(DYp[1][j], wd1, dot2(DYp[0][j], wd0, 1 << (LK_WBITS + 1)));
+                ixv[j] = on ? ixacc : 0; iyv[j] = on ? iyacc : 0;
             }
 #pragma unroll
             for (int q = 0; q < NPR; q++) {
-                Ixp[kk][q] = (2 * q + 1 < PPL) ? pack_lo16(ixv[2 * q], ixv[2 * q + 1]) : ((unsigned)ixv[2 * q] & 0xFFFFu);
-                Iyp[kk][q] = (2 * q + 1 < PPL) ? pack_lo16(iyv[2 * q], iyv[2 * q + 1]) : ((unsigned)iyv[2 * q] & 0xFFFFu);
+                Ixp[kk][q] = (2 * q + 1 < PPL) ? pack_hi16(ixv[2 * q], ixv[2 * q + 1]) : ((unsigned)ixv[2 * q] >> 16);
+                Iyp[kk][q] = (2 * q + 1 < PPL) ? pack_hi16(iyv[2 * q], iyv[2 * q + 1]) : ((unsigned)iyv[2 * q] >> 16);
                 if (kk == 0 && q == 0) { pA11 = dot2_keep(Ixp[0][0], Ixp[0][0], 0); pA12 = dot2_keep(Ixp[0][0], Iyp[0][0], 0); pA22 = dot2_keep(Iyp[0][0], Iyp[0][0], 0); }
                 else { pA11 = dot2(Ixp[kk][q], Ixp[kk][q], pA11); pA12 = dot2(Ixp[kk][q], Iyp[kk][q], pA12); pA22 = dot2(Iyp[kk][q], Iyp[kk][q], pA22); }
             }
