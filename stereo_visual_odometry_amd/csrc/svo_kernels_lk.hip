@@ -552,12 +552,11 @@ __device__ __forceinline__ LkCrit make_crit(const svo_config& c, float mineig_cu
 #define LK_MAP_STRIPE 0
 #define LK_MAP_AFFINE 1
 #define LK_MAP_INTERLEAVED 2
-// Registers: the headline instantiation (w = 21, one feature per wave, single channel) is asked to fit five waves per SIMD;
-// it does so in 91 VGPRs without scratch; w = 31 fits three (150 VGPRs).  The others keep the compiler's default (any
-// further wave would spill).
-#define LK_MIN_WAVES(W, G, CN) (((W) == 21 && (G) == 64 && (CN) == 1) ? 5 : ((W) == 31 && (G) == 64 && (CN) == 1) ? 3 : 1)
+// Register budget: left to the compiler (w = 21: 104 VGPRs, four waves per SIMD).  Asking for a fifth wave (91 VGPRs, no
+// scratch) or for a third at w = 31 was measured on one box against this build and is not faster — 1 % slower at the
+// default two-context configuration, where the other kernels' waves have to fit beside LK's; a sixth wave spills.
 template <int W, int G, int CN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LK_MIN_WAVES(W, G, CN), 8))) void k_lk_chain(DevBuffers d, int slots, int mode, int chunk) {
+__global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mode, int chunk) {
     constexpr int FPW = 64 / G;                                       // features per wave (= per block)
     int seq, fb;
     if (mode == LK_MAP_AFFINE) {
