@@ -77,21 +77,47 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
 
+    # ---- launch contract.  N > 1 is one process per GPU.  The driver normally starts the ranks itself
+    # (python -m torch.distributed.run ... bench.py --gpus N): then WORLD_SIZE is set and must equal --gpus.  When
+    # `python bench.py --gpus N` is run bare, this process starts the N ranks as a FRESH CHILD (never an exec, and before
+    # torch or HIP has been touched here), relays the child's output (rank 0's JSON line) and exits with its status.
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU: python -m torch.distributed.run "
+                         "--nproc-per-node %d bench.py --gpus %d, or run `python bench.py --gpus %d` bare)"
+                         % (args.gpus, world, args.gpus, args.gpus, args.gpus))
+
     import torch
     import torch.distributed as dist
     from stereo_visual_odometry_amd import api, sharding, synthetic as syn
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.same_device:
         local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if not args.same_device and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --gpus %d needs %d GPUs on this node, %d visible" % (world, world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # a process group exists for N > 1, and for a 1-rank rehearsal of the exchange on one GPU (SVO_BENCH_FORCE_GROUP=1:
+    # init, warm-up gather, timed gather and the all-reduces all go through RCCL with a single rank)
+    grouped = world > 1 or os.environ.get("SVO_BENCH_FORCE_GROUP", "") == "1"
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("WORLD_SIZE", str(world)); os.environ.setdefault("RANK", str(rank))
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -169,22 +195,22 @@ def main():
             col += 1
 
     run(0, args.warmup + 1, False)                           # frame 0 only primes the pipeline (vo.cpp:47-56), then W warm-up steps
-    if world > 1:
+    if grouped:
         # warm-up of the exchange as well: the first gather / all-reduce set up RCCL's point-to-point channels
         sharding.gather_pose_streams(torch.zeros(poses.shape, dtype=torch.float64, device=comm_dev), dst=0)
         dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=comm_dev), op=dist.ReduceOp.MAX)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     t0 = time.perf_counter()
     run(args.warmup + 1, args.steps, True)
-    if world > 1:                                            # the path's only exchange: pose streams -> rank 0 (RCCL over xGMI)
+    if grouped:                                              # the path's only exchange: pose streams -> rank 0 (RCCL over xGMI)
         gathered = sharding.gather_pose_streams(torch.from_numpy(poses).to(comm_dev), dst=0)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -195,8 +221,9 @@ def main():
         n_ok_all = n_ok
 
     if rank == 0:
-        if world > 1:                                         # rank 0 now holds every sequence's pose stream
+        if grouped:                                           # rank 0 now holds every sequence's pose stream
             assert len(gathered) == world and all(tuple(g.shape) == (B, args.steps, 17) for g in gathered)
+            assert np.array_equal(gathered[0].cpu().numpy(), poses)
         N = float(np.mean(n_lk))
         bytes_total, bytes_lk = algorithmic_bytes(W, H, N, win, over["max_level"], over["ransac_iterations"])
         lk_avg_ms = float(np.mean(lk_ms))
@@ -279,7 +306,7 @@ def main():
             "cpu_baseline": cpu, "ate": ate,
         }
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

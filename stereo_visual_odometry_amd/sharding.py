@@ -29,9 +29,9 @@ def gather_pose_streams(local, dst=0):
     Returns on rank dst a list (len world_size) of tensors, None elsewhere.  Equal shapes on all ranks
     (weak scaling: every rank owns the same number of sequences and frames)."""
     import torch.distributed as dist
-    world = dist.get_world_size()
-    if world == 1:
-        return [local]
+    if not dist.is_initialized():
+        return [local]                       # single process, no process group: nothing to exchange
+    world = dist.get_world_size()            # a 1-rank group still goes through the collective (RCCL rehearsal on one GPU)
     rank = dist.get_rank()
     out = [local.new_empty(local.shape) for _ in range(world)] if rank == dst else None
     dist.gather(local, out, dst=dst)
@@ -51,7 +51,8 @@ def gather_ragged_pose_streams(streams, dst=0, device=None):
     dev = device if device is not None else torch.device("cpu")
     n_local = torch.tensor([len(streams)], dtype=torch.int64, device=dev)
     max_len = torch.tensor([max([len(x) for x in streams], default=0)], dtype=torch.int64, device=dev)
-    if world > 1:
+    grouped = dist.is_initialized()                              # a 1-rank group still runs every collective
+    if grouped:
         dist.all_reduce(n_local, op=dist.ReduceOp.MAX)           # ranks may own different numbers of sequences
         dist.all_reduce(max_len, op=dist.ReduceOp.MAX)
     S, F = int(n_local.item()), int(max_len.item())
@@ -60,7 +61,7 @@ def gather_ragged_pose_streams(streams, dst=0, device=None):
         block[k, :len(x)] = x
         lens[k] = len(x)
     tb = torch.from_numpy(block).to(dev); tl = torch.from_numpy(lens).to(dev)
-    if world > 1:
+    if grouped:
         ob = [torch.empty_like(tb) for _ in range(world)] if rank == dst else None
         ol = [torch.empty_like(tl) for _ in range(world)] if rank == dst else None
         dist.gather(tb, ob, dst=dst)

@@ -1,0 +1,64 @@
+"""The path's only exchange on hardware: a 1-rank RCCL ("nccl") process group on the MI355X runs the pose-stream gathers
+with device tensors, including the int64 all-reduces of the ragged form (BASELINE configs[3]; SURVEY.md §8e — new design,
+the reference has no collective).  Each case runs in a child process so the group never leaks into the other GPU tests.
+More ranks cannot share one card under RCCL; the N > 1 layout is covered by tests/test_sharding_gloo.py (gloo, 2 ranks)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from stereo_visual_odometry_amd import sharding
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29541"
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+rng = np.random.default_rng(7)
+local = rng.normal(size=(3, 6, 17))
+out = sharding.gather_pose_streams(torch.from_numpy(local).to(dev), dst=0)
+assert len(out) == 1 and out[0].is_cuda and np.array_equal(out[0].cpu().numpy(), local)
+lens = [27, 11, 46]
+streams = [rng.normal(size=(n, 17)) for n in lens]
+rag = sharding.gather_ragged_pose_streams(streams, dst=0, device=dev)
+assert sorted(rag) == [0, 1, 2] and all(np.array_equal(rag[k], streams[k]) for k in range(3))
+empty = sharding.gather_ragged_pose_streams([], dst=0, device=dev)
+assert empty == {}
+t = torch.tensor([3.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t.item()) == 3.5
+dist.barrier()
+dist.destroy_process_group()
+print(json.dumps({"ok": True, "backend": "nccl"}))
+"""
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def test_rccl_world1_pose_gathers_on_device():
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == {"ok": True, "backend": "nccl"}
+
+
+def test_bench_runs_its_exchange_through_rccl():
+    """bench.py with a forced 1-rank group: init_process_group("nccl"), the warm-up gather, the timed gather of the pose
+    streams and the all-reduces all execute on the device; the line still says n_gpus 1."""
+    env = _env(); env["SVO_BENCH_FORCE_GROUP"] = "1"; env["MASTER_PORT"] = "29543"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--seqs", "8",
+                        "--contexts", "1", "--cpu-frames", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["pose_ok_fraction"] > 0.9
