@@ -166,19 +166,35 @@ __device__ __forceinline__ unsigned pack_lo16(int lo, int hi) { return __builtin
 typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void lk_weights(float a, float b, unsigned& w0, unsigned& w1) {
     const float MAGIC = 12582912.f;                                   // 1.5 * 2^23, bits 0x4B400000
+    const float SC = (float)(1 << LK_WBITS);
     const float2v ab = {a, b};
     const float2v om = 1.f - ab;                                      // (1-a, 1-b)
-    float2v A = {om.x, ab.x};
-    A *= (float)(1 << LK_WBITS);                                      // ((1-a) 2^14, a 2^14), exact
-    const float2v p = A * om.y + MAGIC;                               // iw00, iw01 as magic floats
-    const float q = A.x * ab.y + MAGIC;                               // iw10
-    const unsigned m00 = __float_as_uint(p.x), m01 = __float_as_uint(p.y), m10 = __float_as_uint(q);
+    // (a (1-b), b (1-a)) = iw01, iw10 before scaling: ONE packed multiply of (a, b) with the swapped (1-b, 1-a).  The products
+    // are the same two floats whichever factor carries the 2^14 (a power of two moves through the rounding), and x * 2^14 is
+    // exact, so the fused multiply-add below rounds exactly where "x * 2^14 + MAGIC" in two steps does.
+    const float2v om_sw = {om.y, om.x};
+    const float2v cross = ab * om_sw;
+    const float p00 = om.x * om.y;
+    const float2v mc = __builtin_elementwise_fma(cross, (float2v){SC, SC}, (float2v){MAGIC, MAGIC});   // iw01, iw10 as magic floats
+    const float m0 = __builtin_fmaf(p00, SC, MAGIC);                                                   // iw00
+    const unsigned m00 = __float_as_uint(m0), m01 = __float_as_uint(mc.x), m10 = __float_as_uint(mc.y);
     const unsigned iw11 = ((1u << LK_WBITS) + 3u * 0x4B400000u) - (m00 + m01 + m10);
     w0 = pack_lo16((int)m00, (int)m01);
     w1 = pack_lo16((int)m10, (int)iw11);
 }
 
-struct LkCrit { int max_count; double eps2; float mineig_cut; };
+// eps_hi / eps_lo bracket eps2 for the f32 screening of the convergence test (see newton_step)
+struct LkCrit { int max_count; double eps2; float mineig_cut; float eps_hi, eps_lo; };
+// With G == 64 every per-feature quantity is identical in all lanes of the wave, so every branch on one is wave-uniform.
+// The compiler cannot prove that (the values live in VGPRs) and would guard each branch with exec-mask bookkeeping and keep
+// loop counters in VGPRs; a ballot of the condition IS uniform by construction and costs nothing extra (v_cmp writes an
+// SGPR pair either way): branches become s_cbranch, counters become SALU.  Groups smaller than a wave keep plain SIMT.
+template <int G> __device__ __forceinline__ bool uni(bool c) {
+    if constexpr (G == 64) return __builtin_amdgcn_ballot_w64(c) != 0ull; else return c;
+}
+template <int G> __device__ __forceinline__ int uni_i(int v) {
+    if constexpr (G == 64) return __builtin_amdgcn_readfirstlane(v); else return v;
+}
 template <int SPL> struct LkSegs { int row[SPL]; int xs[SPL]; bool on[SPL]; };   // the window segments a lane owns
 
 typedef short short2v __attribute__((ext_vector_type(2)));
@@ -381,20 +397,24 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             if (level == 0) status = 0;
             continue;
         }
-        Dt = 1.f / Dt;
+        // the 2^-20 scale of the mismatch sums is folded into 1/D once per level: scaling by a power of two commutes with
+        // every rounding below (no overflow: |A12 b| < 2^52; no underflow: 1/D >= 2^-41), so the steps skip that multiply
+        const float Dts = (1.f / Dt) * FLT_SCALE;
         nx -= half; ny -= half;
         // Newton iterations.  The search window (two rows of packed byte pairs per segment) lives in registers and is
         // re-loaded only when the INTEGER window origin floor(n) changes; most iterations move the window by a fraction of
         // a pixel and touch no memory.
         int j = 0;
-        float pdx = 0.f, pdy = 0.f;
+        float pdx = 0.f, pdy = 0.f, ldx = 0.f, ldy = 0.f;
+        bool moved = false, osc = false;
         unsigned P0[KS][PPL], P1[KS][PPL];
         auto load_window = [&](int inx, int iny) __attribute__((always_inline)) {
-            if (inx >= 0 && inx + EXT < L.w && iny >= 0 && iny + W < L.h) {
+            if (uni<G>(inx >= 0 && inx + EXT < L.w && iny >= 0 && iny + W < L.h)) {
+                const uint8_t* base = Bm + (size_t)uni_i<G>(iny) * L.w + uni_i<G>(inx);
 #pragma unroll
                 for (int kk = 0; kk < KS; kk++) {
                     const int k = kk % SPL;
-                    const uint8_t* p = Bm + (size_t)(kk / SPL) * pstride + (size_t)(iny + sg.row[k]) * L.w + (inx + sg.xs[k]);
+                    const uint8_t* p = base + (size_t)(kk / SPL) * pstride + (unsigned)(sg.row[k] * L.w + sg.xs[k]);
                     load_pairs<NB>(p, P0[kk]);
                     load_pairs<NB>(p + L.w, P1[kk]);
                 }
@@ -416,9 +436,10 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 }
             }
         };
-        // one Newton step against the window loaded at integer origin (fx0, fy0); returns true when the track is finished
-        auto newton_step = [&](float fx0, float fy0) __attribute__((always_inline)) -> bool {
-            lk_weights(nx - fx0, ny - fy0, w0, w1);
+        // one Newton step with the window loaded at the integer origin the fractions (fa, fb) = n - origin refer to;
+        // returns true when the track is finished at this level
+        auto newton_step = [&](float fa, float fb) __attribute__((always_inline)) -> bool {
+            lk_weights(fa, fb, w0, w1);
             int pb1 = 0, pb2 = 0;
 #pragma unroll
             for (int kk = 0; kk < KS; kk++) {
@@ -452,15 +473,20 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 if (nar) group_sums_to_float_narrow<G, 2>(pb, bs);
                 else group_sums_to_float<G, 2, PRE>(pb, bs);
             }
-            const float b1 = bs[0] * FLT_SCALE, b2 = bs[1] * FLT_SCALE;
-            const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
+            const float dx = (A12 * bs[1] - A22 * bs[0]) * Dts, dy = (A12 * bs[0] - A11 * bs[1]) * Dts;
             nx += dx; ny += dy;
-            outx = nx + half; outy = ny + half;
-            if ((double)dx * (double)dx + (double)dy * (double)dy <= crit.eps2) return true;
+            ldx = dx; ldy = dy; moved = true;
+            // termination on |delta|^2 <= eps^2, an f64 comparison in lkpyramid.cpp.  The f32 sum of squares is within 2e-7
+            // (relative) of the exact one, so away from the threshold it decides; the f64 form only runs in the gap.
+            const float s32 = dx * dx + dy * dy;
+            if (!uni<G>(s32 > crit.eps_hi)) {
+                if (uni<G>(s32 < crit.eps_lo)) return true;
+                if (uni<G>((double)dx * (double)dx + (double)dy * (double)dy <= crit.eps2)) return true;
+            }
             // "(double)|v| < 0.01" for a float v is exactly "|v| < nextafterf((float)0.01)": 0.01 lies between the floats
             // 0x3C23D70A and 0x3C23D70B, so v < 0.01 (as doubles) <=> v <= 0x3C23D70A <=> v < 0x3C23D70B
-            if (j > 0 && fabsf(dx + pdx) < 0.010000000707805157f && fabsf(dy + pdy) < 0.010000000707805157f) {
-                outx -= dx * 0.5f; outy -= dy * 0.5f;
+            if (j > 0 && uni<G>(fabsf(dx + pdx) < 0.010000000707805157f) && uni<G>(fabsf(dy + pdy) < 0.010000000707805157f)) {
+                osc = true;                                                  // nextPts -= delta * 0.5 (applied after the loop)
                 return true;
             }
             pdx = dx; pdy = dy;
@@ -472,15 +498,20 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             bool stop = crit.max_count <= 0;
             while (!stop) {
                 const int inx = (int)floorf(nx), iny = (int)floorf(ny);
-                if (inx < -W || inx >= L.w || iny < -W || iny >= L.h) {
+                if (uni<G>(inx < -W || inx >= L.w || iny < -W || iny >= L.h)) {
                     if (level == 0) status = 0;
                     break;
                 }
                 load_window(inx, iny);
                 const float fx0 = (float)inx, fy0 = (float)iny;
+                float fa = nx - fx0, fb = ny - fy0;
                 for (;;) {
-                    if (newton_step(fx0, fy0)) { stop = true; break; }
-                    if (floorf(nx) != fx0 || floorf(ny) != fy0) break;                 // integer origin moved: new epoch (exact: |n| < 2^24)
+                    if (newton_step(fa, fb)) { stop = true; break; }
+                    // same epoch <=> floor(n) == origin <=> 0 <= n - origin < 1.  The difference is exact there (|n| < 2^23, so it is
+                    // a multiple of ulp(n) below 1: at most 24 bits) and rounding is monotone elsewhere; a float in [0, 1) is exactly
+                    // a bit pattern below 0x3F800000 (negatives have the sign bit set)
+                    fa = nx - fx0; fb = ny - fy0;
+                    if (uni<G>(__float_as_uint(fa) >= 0x3F800000u || __float_as_uint(fb) >= 0x3F800000u)) break;
                 }
             }
         } else {
@@ -500,8 +531,12 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                     }
                     load_window(inx, iny);
                 }
-                if (newton_step((float)inx, (float)iny)) break;
+                if (newton_step(nx - (float)inx, ny - (float)iny)) break;
             }
+        }
+        if (moved) {                                                         // nextPts[i] = nextPt + halfWin (every iteration in lkpyramid.cpp)
+            outx = nx + half; outy = ny + half;
+            if (osc) { outx -= ldx * 0.5f; outy -= ldy * 0.5f; }
         }
         // flags = 0 with err != NULL (vo.cpp:182,203): the level-0 error block re-checks the final window origin
         if (status && level == 0) {
@@ -531,6 +566,10 @@ __device__ __forceinline__ LkCrit make_crit(const svo_config& c, float mineig_cu
     int mc = c.lk_max_count; mc = mc < 0 ? 0 : (mc > 100 ? 100 : mc);       // TermCriteria normalisation (lkpyramid.cpp)
     double e = c.lk_epsilon; e = e < 0. ? 0. : (e > 10. ? 10. : e);
     k.max_count = mc; k.eps2 = e * e; k.mineig_cut = mineig_cut;
+    // f32 screen of "dx^2 + dy^2 <= eps2" (the f32 sum is within 2e-7 relative of the exact one): above eps_hi certainly not
+    // converged, below eps_lo certainly converged, in between (practically never) the exact f64 comparison decides
+    if (k.eps2 > 1e-30) { k.eps_hi = (float)(k.eps2 * 1.00001); k.eps_lo = (float)(k.eps2 * 0.99999); }
+    else { k.eps_hi = __builtin_inff(); k.eps_lo = -1.f; }                        // tiny epsilon: always the exact path
     return k;
 }
 
