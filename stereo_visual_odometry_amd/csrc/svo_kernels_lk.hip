@@ -149,6 +149,42 @@ __device__ __forceinline__ void group_sums_to_float_narrow(const int (&partial)[
     for (int i = 0; i < N; i++) out[i] = (float)dpp_cross_rows<G>(u[i]);
 }
 
+// ---- wave-wide (G == 64) sums of TWO values at once.  v_permlane32_swap exchanges the upper 32 lanes of one register with
+// the lower 32 of another: after it, (r0 + r1) holds a's 32 pairwise partials in lanes 0..31 and b's in lanes 32..63, so every
+// following DPP step reduces both values in one instruction (rows 0-1 belong to a, rows 2-3 to b; row_bcast:15 joins each
+// pair of rows).  7 VALU instructions + 2 v_readlane instead of 12 + 2.
+__device__ __forceinline__ int wave_fold2(int a, int b) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    return (int)(r[0] + r[1]);
+}
+__device__ __forceinline__ int wave_join_rows2(int u) {                 // after the four row steps: lane 31 = a's total, lane 63 = b's
+    return u + __builtin_amdgcn_update_dpp(0, u, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+}
+__device__ __forceinline__ void wave_sums2_narrow(int a, int b, float& fa, float& fb) {
+    int u = wave_fold2(a, b);
+    u = dpp_row_step<0>(u); u = dpp_row_step<1>(u); u = dpp_row_step<2>(u); u = dpp_row_step<3>(u);
+    u = wave_join_rows2(u);
+    fa = (float)__builtin_amdgcn_readlane(u, 31); fb = (float)__builtin_amdgcn_readlane(u, 63);
+}
+// wide form (any input): the fold and PRE - 1 row steps happen on the int32 partials (PRE doublings cannot overflow), then the
+// register is split into 16-bit halves whose sums fit 23 bits
+template <int PRE>
+__device__ __forceinline__ void wave_sums2_wide(int a, int b, float& fa, float& fb) {
+    static_assert(PRE >= 1, "the fold is one doubling");
+    int u = wave_fold2(a, b);
+    if (PRE > 1) u = dpp_row_step<0>(u);
+    if (PRE > 2) u = dpp_row_step<1>(u);
+    if (PRE > 3) u = dpp_row_step<2>(u);
+    int lo = u & 0xFFFF, hi = u >> 16;
+    if (PRE < 2) { lo = dpp_row_step<0>(lo); hi = dpp_row_step<0>(hi); }
+    if (PRE < 3) { lo = dpp_row_step<1>(lo); hi = dpp_row_step<1>(hi); }
+    if (PRE < 4) { lo = dpp_row_step<2>(lo); hi = dpp_row_step<2>(hi); }
+    lo = dpp_row_step<3>(lo); hi = dpp_row_step<3>(hi);
+    lo = wave_join_rows2(lo); hi = wave_join_rows2(hi);
+    fa = (float)__builtin_amdgcn_readlane(hi, 31) * 65536.f + (float)__builtin_amdgcn_readlane(lo, 31);
+    fb = (float)__builtin_amdgcn_readlane(hi, 63) * 65536.f + (float)__builtin_amdgcn_readlane(lo, 63);
+}
+
 // (upper half of a, lower half of b) as one packed pair
 __device__ __forceinline__ unsigned hi_lo16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040302u); }
 // upper halves of two registers -> one packed pair
@@ -380,8 +416,15 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             const bool big = ((unsigned)pA11 | (unsigned)pA22) >= (1u << 25);
             const unsigned long long bigs = __builtin_amdgcn_ballot_w64(big);
             const bool nar = G == 64 ? bigs == 0ull : ((bigs >> ((threadIdx.x / G) * G)) & ((G == 64 ? 0ull : (1ull << (G & 63))) - 1ull)) == 0ull;
-            if (nar) group_sums_to_float_narrow<G, 3>(pa, As);
-            else group_sums_to_float<G, 3, PRE>(pa, As);
+            if constexpr (G == 64 && PRE >= 1) {
+                const int p1[1] = {pA12}; float a1[1];
+                if (nar) { wave_sums2_narrow(pA11, pA22, As[0], As[2]); group_sums_to_float_narrow<G, 1>(p1, a1); }
+                else { wave_sums2_wide<PRE>(pA11, pA22, As[0], As[2]); group_sums_to_float<G, 1, PRE>(p1, a1); }
+                As[1] = a1[0];
+            } else {
+                if (nar) group_sums_to_float_narrow<G, 3>(pa, As);
+                else group_sums_to_float<G, 3, PRE>(pa, As);
+            }
         }
         // |sum diff*Ix| <= 8160 * sqrt(CN W^2 * sum Ix^2) (Cauchy-Schwarz): below 2^31 when sum Ix^2 < 2^62 / (8160^2 CN W^2); 5 % margin
         // covers the float rounding of As.  Then the mismatch sums never leave int32 and take the narrow reduction.
@@ -470,8 +513,13 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                     const unsigned long long bigs = __builtin_amdgcn_ballot_w64(big);
                     nar = G == 64 ? bigs == 0ull : ((bigs >> ((threadIdx.x / G) * G)) & ((G == 64 ? 0ull : (1ull << (G & 63))) - 1ull)) == 0ull;
                 }
-                if (nar) group_sums_to_float_narrow<G, 2>(pb, bs);
-                else group_sums_to_float<G, 2, PRE>(pb, bs);
+                if constexpr (G == 64 && PRE >= 1) {
+                    if (nar) wave_sums2_narrow(pb1, pb2, bs[0], bs[1]);
+                    else wave_sums2_wide<PRE>(pb1, pb2, bs[0], bs[1]);
+                } else {
+                    if (nar) group_sums_to_float_narrow<G, 2>(pb, bs);
+                    else group_sums_to_float<G, 2, PRE>(pb, bs);
+                }
             }
             const float dx = (A12 * bs[1] - A22 * bs[0]) * Dts, dy = (A12 * bs[0] - A11 * bs[1]) * Dts;
             nx += dx; ny += dy;
