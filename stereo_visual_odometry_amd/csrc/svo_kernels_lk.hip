@@ -293,7 +293,8 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         outx = nx; outy = ny;
         ppx -= half; ppy -= half;
         const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
-        if (ipx < -W || ipx >= L.w || ipy < -W || ipy >= L.h) {
+        // -W <= ip < size  <=>  (unsigned)(ip + W) < (unsigned)(size + W): one compare per axis
+        if (uni<G>(ipx < -W || ipx >= L.w || ipy < -W || ipy >= L.h)) {
             if (level == 0) status = 0;
             continue;
         }
@@ -313,7 +314,10 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         int Kr[KS][PPL];
         unsigned Ixp[KS][NPR], Iyp[KS][NPR];
         int pA11 = 0, pA12 = 0, pA22 = 0;
-        const bool interior = ipx >= 1 && ipx + EXT + 1 < L.w && ipy >= 1 && ipy + W + 1 < L.h;
+        // 1 <= ipx && ipx + EXT + 1 < w  <=>  (unsigned)(ipx - 1) < (unsigned)(w - EXT - 2)   (a non-positive bound never holds: the image is larger than the window)
+        const bool interior = uni<G>(ipx >= 1 && ipx + EXT + 1 < L.w && ipy >= 1 && ipy + W + 1 < L.h);
+        // interior windows: one (wave-uniform for G == 64) base address per level visit, 32-bit lane offsets
+        const uint8_t* __restrict__ Abase = A + (size_t)(uni_i<G>(ipy) - 1) * L.w + (uni_i<G>(ipx) - 1);
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) {
             const int k = kk % SPL;
@@ -324,9 +328,9 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             // their bytes through REFLECT_101 (the border of the pyramid level) — everything after that is shared
             unsigned Q[4][NS - 1];
             if (interior) {
-                const uint8_t* p = Ap + (size_t)(ipy - 1 + row) * L.w + (ipx - 1 + xs);
+                const uint8_t* p = Abase + (size_t)(kk / SPL) * pstride + (unsigned)(row * L.w + xs);
 #pragma unroll
-                for (int r = 0; r < 4; r++) load_pairs<NS>(p + (size_t)r * L.w, Q[r]);
+                for (int r = 0; r < 4; r++) load_pairs<NS>(p + (unsigned)(r * L.w), Q[r]);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -436,7 +440,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         // host found by bisection over the floats (lk_mineig_cut): division by a positive constant is monotone, so
         // "(double)fl(num / den) < threshold"  <=>  "num < cut" exactly.
         const float eig_num = A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12);
-        if (eig_num < crit.mineig_cut || Dt < 1.1920928955078125e-07f) {
+        if (uni<G>(eig_num < crit.mineig_cut || Dt < 1.1920928955078125e-07f)) {
             if (level == 0) status = 0;
             continue;
         }
