@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string>
 #include <vector>
+#include <math.h>
 
 static thread_local std::string g_err;
 extern "C" const char* svo_last_error(void) { return g_err.c_str(); }
@@ -133,6 +134,16 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     ALLOC(d.tl0, B * CAP); ALLOC(d.tr0, B * CAP); ALLOC(d.tl1, B * CAP); ALLOC(d.tr1, B * CAP);
     ALLOC(d.world, B * CAP * 3); ALLOC(d.inlier, B * CAP); ALLOC(d.inl_idx, B * CAP);
     ALLOC(d.subsets, B * (size_t)d.K * 5); ALLOC(d.hyp, B * (size_t)d.K * 12); ALLOC(d.hyp_good, B * (size_t)d.K);
+    {
+        double* lam = nullptr;
+        ALLOC(lam, 33);
+        double h[33];
+        const double LOG10 = log(10.);
+        for (int k = -16; k <= 16; k++) h[k + 16] = exp(k * LOG10);      // CvLevMarq: lambda = exp(lambdaLg10 * log(10))
+        HIPCHK(hipMemcpyAsync(lam, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));                          // h is a stack array
+        d.lm_lambda = lam;
+    }
     ALLOC(d.results, (size_t)SVO_RING * B);
     ALLOC(d.img_ptrs, (size_t)SVO_RING * 2 * B);
 #undef ALLOC
@@ -620,6 +631,7 @@ extern "C" int svo_camera_to_world(int device, const float K[9], int n, const fl
     HIPCHK(hipMemcpyAsync(c->d.tl1, cam_pts, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d.world, world_pts, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
     if ((rc = set_state(c, hs)) != SVO_OK) return rc;
+    launch_pnp_subsets(c->d, c->stream);
     launch_pnp(c->d, c->stream);
     HIPCHK(hipGetLastError());
     if ((rc = read_state(c, 0, &hs)) != SVO_OK) return rc;

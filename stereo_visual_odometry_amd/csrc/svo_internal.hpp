@@ -65,6 +65,7 @@ struct DevBuffers {
     double* hyp;                               // [B][K][12]  (R row-major, t)
     int* hyp_good;                             // [B][K]
     int* inl_idx;                              // [B][CAP]
+    const double* lm_lambda;                   // [33] 10^k, k = -16..16 (the damping factors CvLevMarq can reach), computed on the host
     FrameResult* results;                      // [SVO_RING][B]
     const uint8_t** img_ptrs;                  // [SVO_RING][2][B] device array of source image pointers
 };
@@ -85,7 +86,8 @@ void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s
 void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t s);      // grid_n = max features that can enter LK
 void launch_compact(const DevBuffers& d, hipStream_t s);
 void launch_triangulate(const DevBuffers& d, hipStream_t s);
-void launch_pnp(const DevBuffers& d, hipStream_t s);
+void launch_pnp(const DevBuffers& d, hipStream_t s);                   // expects the subsets drawn (launch_triangulate does it)
+void launch_pnp_subsets(const DevBuffers& d, hipStream_t s);
 void launch_inverse_transform(const double* R, const double* t, double* T, hipStream_t s);   // device pointers
 void launch_frame_end(const DevBuffers& d, int ring_slot, hipStream_t s);
 

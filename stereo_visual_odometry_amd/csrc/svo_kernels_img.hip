@@ -392,15 +392,17 @@ __global__ void k_bucket_offer_old(DevBuffers d, int pass) {
     }
 }
 
-// one 256-thread block per sequence (small enough to be placed beside another context's LK waves):
-// scan the grid in raster order, emit winners
+// one block per sequence: scan the grid in raster order, emit winners.  1024 threads: the serial part of a thread is 15 keys
+// (it was 58 with 256 threads, 50 us at one sequence), which is what bounds the kernel when a single stream runs alone.
 #define SCAN_THREADS 256
 #define SCAN_WAVES (SCAN_THREADS / 64)
-__global__ __launch_bounds__(SCAN_THREADS) void k_bucket_emit(DevBuffers d, int pass) {
+#define EMIT_THREADS 1024
+#define EMIT_WAVES (EMIT_THREADS / 64)
+__global__ __launch_bounds__(EMIT_THREADS) void k_bucket_emit(DevBuffers d, int pass) {
     const int seq = blockIdx.x;
     SeqState& s = d.st[seq];
     if (pass == 0 ? !s.active : !s.do_second) return;
-    __shared__ int wave_tot[SCAN_WAVES];
+    __shared__ int wave_tot[EMIT_WAVES];
     __shared__ int s_total;
     const int fb = s.feat_buf, nb = d.NB, n_old = s.n_old, W = d.geom.W;
     const unsigned long long* keys = d.bucket_keys + (size_t)seq * nb;
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_bucket_emit(DevBuffers d, int 
     float2* nxy = d.feat_xy[fb ^ 1] + (size_t)seq * d.CAP;
     int* nage = d.feat_age[fb ^ 1] + (size_t)seq * d.CAP;
     int* nstr = d.feat_str[fb ^ 1] + (size_t)seq * d.CAP;
-    const int chunk = (nb + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int chunk = (nb + EMIT_THREADS - 1) / EMIT_THREADS;
     const int b0 = threadIdx.x * chunk < nb ? threadIdx.x * chunk : nb, b1 = (b0 + chunk < nb) ? b0 + chunk : nb;
     int cnt = 0;
     for (int b = b0; b < b1; b++) cnt += keys[b] != 0ull;
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_bucket_emit(DevBuffers d, int 
     for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
     if (lane == 63) wave_tot[wv] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < SCAN_WAVES; i++) { int t = wave_tot[i]; wave_tot[i] = acc; acc += t; } s_total = acc; }
+    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < EMIT_WAVES; i++) { int t = wave_tot[i]; wave_tot[i] = acc; acc += t; } s_total = acc; }
     __syncthreads();
     int pos = wave_tot[wv] + incl - cnt;
     for (int b = b0; b < b1; b++) {
@@ -454,7 +456,7 @@ void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s
     hipLaunchKernelGGL(k_bucket_offer_old, dim3((d.CAP + 255) / 256, d.B), dim3(256), 0, st, d, pass);
     dim3 g((d.geom.W + FT_W - 1) / FT_W, (d.geom.H + FT_H - 1) / FT_H, d.B);
     hipLaunchKernelGGL(k_fast<true>, g, dim3(256), 0, st, (const uint8_t*)nullptr, 0, 0, (uint8_t*)nullptr, d, pass, th);
-    hipLaunchKernelGGL(k_bucket_emit, dim3(d.B), dim3(SCAN_THREADS), 0, st, d, pass);
+    hipLaunchKernelGGL(k_bucket_emit, dim3(d.B), dim3(EMIT_THREADS), 0, st, d, pass);
 }
 
 // ------------------------------------------------------------------------------------------------

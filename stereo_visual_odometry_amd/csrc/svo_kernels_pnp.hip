@@ -20,10 +20,17 @@ static __device__ __forceinline__ bool seq_live(const SeqState& s) { return s.ac
 static __device__ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
 
 // ------------------------------------------------------------------------------------------------ triangulation
+// The last block of every sequence does not triangulate: its first lane draws the RANSAC subsets (they depend on the
+// track count only), so the serial RNG walk hides under the triangulation instead of being a launch of its own.
+static __device__ void pnp_draw_subsets(const DevBuffers& d, int seq, unsigned n);
 __global__ __launch_bounds__(64) void k_triangulate(DevBuffers d) {
     const int seq = blockIdx.y;
     const SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
+    if (blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x == 0) pnp_draw_subsets(d, seq, (unsigned)s.n_tracks);
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.n_tracks) return;
     const size_t o = (size_t)seq * d.CAP + i;
@@ -42,17 +49,18 @@ __global__ __launch_bounds__(64) void k_triangulate(DevBuffers d) {
     d.world[3 * o] = X * scale; d.world[3 * o + 1] = Y * scale; d.world[3 * o + 2] = Z * scale;
 }
 void launch_triangulate(const DevBuffers& d, hipStream_t st) {
-    hipLaunchKernelGGL(k_triangulate, dim3((d.CAP + 63) / 64, d.B), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(k_triangulate, dim3((d.CAP + 63) / 64 + 1, d.B), dim3(64), 0, st, d);
 }
 
 // ------------------------------------------------------------------------------------------------ subsets (cv::RNG, getSubset)
-__global__ void k_pnp_subsets(DevBuffers d) {
-    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seq >= d.B) return;
-    const SeqState& s = d.st[seq];
-    if (!seq_live(s)) return;
-    const unsigned n = (unsigned)s.n_tracks;
+// All K 5-subsets of one sequence, drawn with cv::RNG's multiply-with-carry recurrence from the seed (uint64)-1; the number
+// of draws never depends on model quality.  uniform(0, n) = next() % n: the remainder is taken through the 64-bit reciprocal
+// ceil(2^64 / n) (exact for 32-bit operands: the error term x e / (n 2^64) stays below 2^-32 < 1/n), 6 instructions instead
+// of the 32-bit division sequence.
+static __device__ void pnp_draw_subsets(const DevBuffers& d, int seq, unsigned n) {
+    if (n < 2) return;
     unsigned long long state = 0xFFFFFFFFFFFFFFFFull;                // RNG rng((uint64)-1)
+    const unsigned long long recip = 0xFFFFFFFFFFFFFFFFull / n + 1ull;
     int* out = d.subsets + (size_t)seq * d.K * 5;
     for (int it = 0; it < d.K; it++) {
         int idx[5];
@@ -60,7 +68,8 @@ __global__ void k_pnp_subsets(DevBuffers d) {
             int v; bool dup;
             do {
                 state = (unsigned long long)(unsigned)state * 4164903690ull + (unsigned)(state >> 32);
-                v = (int)((unsigned)state % n);
+                const unsigned x = (unsigned)state;
+                v = (int)(x - (unsigned)__umul64hi((unsigned long long)x, recip) * n);
                 dup = false;
                 for (int k = 0; k < i; k++) dup |= (idx[k] == v);
             } while (dup);
@@ -68,6 +77,18 @@ __global__ void k_pnp_subsets(DevBuffers d) {
         }
         for (int i = 0; i < 5; i++) out[it * 5 + i] = idx[i];
     }
+}
+
+// stand-alone launch for callers that enter at launch_pnp without a triangulation before it (svo_camera_to_world)
+__global__ void k_pnp_subsets(DevBuffers d) {
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= d.B) return;
+    const SeqState& s = d.st[seq];
+    if (!seq_live(s)) return;
+    pnp_draw_subsets(d, seq, (unsigned)s.n_tracks);
+}
+void launch_pnp_subsets(const DevBuffers& d, hipStream_t st) {
+    hipLaunchKernelGGL(k_pnp_subsets, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
 }
 
 // ------------------------------------------------------------------------------------------------ EPnP on 5 points
@@ -578,6 +599,7 @@ struct LmShared {
     double red[4][28];
     double prevErrNorm;
     int lambdaLg10, iters, state, mode;
+    const double* lambda_tab;
     int wave_tot[4]; int total;
 };
 
@@ -635,7 +657,7 @@ static __device__ void lm_eval(const DevBuffers& d, const SeqState& s, size_t o,
 }
 
 static __device__ void lm_step(LmShared& sh) {
-    const double lambda = exp(sh.lambdaLg10 * log(10.));
+    const double lambda = sh.lambda_tab[sh.lambdaLg10 + 16];          // exp(lambdaLg10 * log(10)), tabulated by the host
     double A[36], x[6];
     for (int i = 0; i < 36; i++) A[i] = sh.JtJ[i];
     for (int i = 0; i < 6; i++) A[7 * i] *= 1. + lambda;
@@ -696,7 +718,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
         rodrigues_to_vector(bestRt, rv);
         sh.param[0] = rv[0]; sh.param[1] = rv[1]; sh.param[2] = rv[2];
         sh.param[3] = bestRt[9]; sh.param[4] = bestRt[10]; sh.param[5] = bestRt[11];
-        sh.lambdaLg10 = -3; sh.iters = 0; sh.state = 0; sh.mode = 1; sh.prevErrNorm = 0;
+        sh.lambdaLg10 = -3; sh.iters = 0; sh.state = 0; sh.mode = 1; sh.prevErrNorm = 0; sh.lambda_tab = d.lm_lambda;
     }
     __syncthreads();
     for (int guard = 0; guard < 1000; guard++) {
@@ -782,7 +804,7 @@ void launch_inverse_transform(const double* R, const double* t, double* T, hipSt
 
 #define PNP_FIRST_CHUNK 16
 void launch_pnp(const DevBuffers& d, hipStream_t st) {
-    hipLaunchKernelGGL(k_pnp_subsets, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
+    // the subsets were drawn by the last block of k_triangulate (stage entry points go through launch_triangulate too)
     const int c0 = d.K < PNP_FIRST_CHUNK ? d.K : PNP_FIRST_CHUNK;
     hipLaunchKernelGGL(k_pnp_epnp, dim3((c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, 0, c0);
     hipLaunchKernelGGL(k_pnp_score, dim3(c0, d.B), dim3(256), 0, st, d, 0, c0);
