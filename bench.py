@@ -68,7 +68,9 @@ def main():
     ap.add_argument("--seqs", type=int, default=256, help="independent stereo sequences batched per GPU")
     ap.add_argument("--depth", type=int, default=4, help="frames kept in flight per context (<= 8)")
     ap.add_argument("--contexts", type=int, default=2, help="sequence groups per GPU, each on its own HIP stream (their kernels overlap)")
-    ap.add_argument("--pool", type=int, default=2, help="distinct synthetic sequences rendered per rank")
+    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic sequences rendered per rank (own seed each)")
+    ap.add_argument("--movers", type=float, default=0.3, help="fraction of the pixels covered by an independently moving foreground layer "
+                    "(RANSAC-PnP outliers; 0 = static scene, the best case for PnP)")
     ap.add_argument("--frames", type=int, default=10, help="frames rendered per pool sequence (ping-pong replay)")
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg5"],
@@ -127,7 +129,7 @@ def main():
     # ---- workload: BASELINE.json configs[1] — KITTI-00 shaped 1241x376, ~2000 FAST features, LK 21x21, maxLevel 3
     win = int(os.environ.get("SVO_BENCH_WIN", "21"))
     WL = {   # calibration, scene parameters, config overrides, description
-        "cfg2": (syn.KITTI00, dict(seed=0x5EED0002, step=0.5, cell_px=float(os.environ.get("SVO_BENCH_CELL", "17.0"))), dict(max_level=3, ransac_iterations=100),
+        "cfg2": (syn.KITTI00, dict(seed=0x5EED0002, step=0.5, cell_px=float(os.environ.get("SVO_BENCH_CELL", "17.4"))), dict(max_level=3, ransac_iterations=100),
                  "BASELINE configs[1]: KITTI-00 calibration, 1241x376, LK 21x21 win, maxLevel 3, 100 RANSAC-PnP iterations"),
         "cfg3": (syn.KITTI00, dict(seed=0x5EED0003, step=0.5, cell_px=12.0), dict(max_level=4, ransac_iterations=1000),
                  "BASELINE configs[2]: KITTI-00 calibration, 1241x376, ~4000 features, LK 21x21 win, maxLevel 4, 1000 RANSAC-PnP iterations"),
@@ -139,7 +141,7 @@ def main():
     over = dict(win_w=win, win_h=win, max_translation_norm=2.0, **cfg_over)
     B, F = args.seqs, args.frames
     seed0 = scene.pop("seed")
-    pool = [syn.StereoSequence(cal=cal, n_frames=F, seed=seed0 + 97 * rank + g, **scene)
+    pool = [syn.StereoSequence(cal=cal, n_frames=F, seed=seed0 + 97 * rank + g, movers=args.movers, **scene)
             for g in range(args.pool)]
     left = torch.stack([torch.from_numpy(np.stack(s.left)) for s in pool]).to(dev)      # (G, F, H, W) u8, resident in HBM
     right = torch.stack([torch.from_numpy(np.stack(s.right)) for s in pool]).to(dev)
@@ -174,6 +176,7 @@ def main():
     depth = max(1, min(args.depth, 8))
     poses = np.zeros((B, args.steps, 17))
     n_lk, n_ok, lk_ms, fr_ms = [], 0, [], []
+    n_bounds, n_inl, n_iters, n_vis, n_stp = [], [], [], [], []
 
     def run(first, count, record):
         nonlocal n_ok
@@ -190,6 +193,11 @@ def main():
                     a, b = vo.last_timing()                  # HIP events on the context's own stream
                     lk_ms.append(a); fr_ms.append(b)
                     n_lk.append(np.mean([s.n_into_lk for s in vo.stats]))
+                    n_bounds.append(np.mean([s.n_after_bounds for s in vo.stats]))
+                    n_inl.append(np.mean([s.n_inliers for s in vo.stats]))
+                    n_iters.append(np.mean([s.ransac_iters for s in vo.stats]))
+                    n_vis.append(np.mean([s.lk_level_visits for s in vo.stats]))
+                    n_stp.append(np.mean([s.lk_newton_steps for s in vo.stats]))
                     n_ok += int(ok.sum())
                     poses[c * Bc:(c + 1) * Bc, col, :16] = T.reshape(Bc, 16); poses[c * Bc:(c + 1) * Bc, col, 16] = ok
             col += 1
@@ -231,7 +239,7 @@ def main():
         value = world * B * args.steps / dt
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
         # separate runs of this same script, profiles/summarize.py), rescaled to this run's sequences per launch
-        traffic = None
+        traffic = None; traffic_src = None
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_lk_chain_pmc.json")))
         profiled = args.workload == "cfg2" and win == 21          # the committed counter passes are of this workload's kernel
@@ -239,6 +247,8 @@ def main():
             try:
                 j = json.load(open(pmcs[-1]))
                 traffic = j["hbm_bytes_per_launch"] * Bc / float(j.get("sequences_per_launch", 32))
+                traffic_src = "committed rocprofv3 --pmc passes, profiles/%s, rescaled from %d to %d sequences per launch" % (
+                    os.path.basename(pmcs[-1]), int(j.get("sequences_per_launch", 32)), Bc)
             except Exception:
                 traffic = None
         # secondary (SURVEY.md 8d asks for the VALU view too, the kernel being instruction-bound): share of the GPU's VALU
@@ -253,9 +263,26 @@ def main():
                         "issue_slot_frac_at_2.4GHz": value / world * N * ipf / (1024 * 2.4e9 / 4)}
             except Exception:
                 valu = None
+        # the LK flop model of SURVEY.md 8d with the MEASURED work terms: 24 w^2 per level visit that builds a template (bilinear
+        # I / Ix / Iy patches, normal matrix) + 10 w^2 per Newton step, against the f32 VALU peak (157.3 TFLOP/s)
+        vis, stp = float(np.mean(n_vis)), float(np.mean(n_stp))
+        lk_flops = win * win * (24.0 * vis + 10.0 * stp)
+        valu_flop = {"lk_flops_per_frame_pair": lk_flops, "level_visits_per_feature": vis / max(N, 1.0), "newton_steps_per_feature": stp / max(N, 1.0),
+                     "peak_TFLOPs": 157.3, "frac_at_job_rate": lk_flops * value / world / 157.3e12,
+                     "frac_in_kernel": lk_flops * Bc / (lk_avg_ms * 1e-3) / 157.3e12}
         cpu = None
         if world == 1 and args.cpu_frames > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
+            # the CPU number is taken with -O3 -march=native, so that build is made HERE, on the machine that
+            # times it (never shipped: a -march=native object from another host may not even run); same IEEE-strict flags
+            # as the checker build, hence the same results
+            import subprocess
+            orc_build = "-O3 -march=native"
+            try:
+                subprocess.check_call(["make", "-B", "-C", os.path.join(ROOT, "oracle"), "-s", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                os.environ["SVO_ORACLE_LIB"] = os.path.join(ROOT, "oracle", "libsvo_oracle_native.so")
+            except Exception:
+                orc_build = "-O2 (the portable checker build: no compiler on this box for the native one)"
             import oracle_lib as orc
 
             cpu_T = {}                                        # step -> 4x4 the oracle returned (slot 0 sees the same frame stream)
@@ -275,8 +302,10 @@ def main():
             allc, cores = cpu_rate(host_cores(), args.cpu_frames)   # every core this process is granted (OpenMP over LK points / image rows)
             orc.set_threads(1)
             cpu = {"value": allc, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-                   "sample": "%d frame pairs of the same 1241x376 synthetic sequence through oracle/ (plain C -O2, OpenMP over the points "
-                             "of each LK pass and over image rows, %d threads); single thread: %.2f frame-pairs/s" % (args.cpu_frames, cores, single)}
+                   "sample": "%d frame pairs of pool sequence 0 of the same workload through oracle/ — this repo's plain-C RESTATEMENT of the "
+                             "reference's pipeline and of the OpenCV 4.5 calls it makes, NOT OpenCV itself (absent from the image) — built %s, "
+                             "OpenMP over the points of each LK pass and over image rows, %d threads; single thread: %.2f frame-pairs/s"
+                             % (args.cpu_frames, orc_build, cores, single)}
         # ATE (the second half of BASELINE.json's metric), outside the timed region: slot 0's pose stream over the timed steps,
         # integrated as frame_pose = frame_pose * T (main.cpp:396), against the renderer's ground truth for the same frame
         # transitions and against the CPU oracle on the steps its bounded sample covers
@@ -295,11 +324,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int64/f32 (LK), f64 (PnP)",
             "data": "synthetic",
-            "config": {"workload": workload_name,
+            "config": {"workload": workload_name + "; max_translation_norm 2.0 (reference 0.1: its gate is tuned for a 3 cm/frame rover, "
+                                   "the scene moves 0.5 m/frame); %.0f %% of the pixels on an independently moving layer" % (100 * args.movers),
                        "sequences_per_gpu": B, "contexts_per_gpu": C, "frames_in_flight": depth, "mean_features_into_lk": N,
+                       "mean_tracks_after_bounds": float(np.mean(n_bounds)), "mean_inliers": float(np.mean(n_inl)),
+                       "mean_ransac_iters": float(np.mean(n_iters)),
+                       "distinct_streams": min(B, args.pool * max(1, (2 * F - 2) // 3)),
+                       "distinct_rendered_sequences": args.pool, "frames_per_sequence": F,
                        "pose_ok_fraction": n_ok_all / float(world * B * args.steps)},
             "roofline": {"bound": "hbm", "kernel": "k_lk_chain<%d>" % win, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "valu_issue": valu,
+                         "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src, "valu_issue": valu, "valu_flop_frac": valu_flop["frac_in_kernel"], "valu_flop": valu_flop,
                          "algorithmic_bytes_per_frame_pair": {"lk_chain": bytes_lk, "whole_frame": bytes_total},
                          "kernel_avg_ms": lk_avg_ms, "frame_avg_ms": float(np.mean(fr_ms)),
                          "whole_frame_frac": bytes_total * value / world / 1e9 / PEAK_HBM_GBS},

@@ -71,6 +71,8 @@ typedef struct {
     int ransac_iters;       /* iterations the adaptive RANSAC loop would have run */
     int fail_reason;        /* 0 ok, 1 first frame, 2 too few tracks (vo.cpp:82), 3 RANSAC fail / few inliers (:106), 4 motion gate (:129) */
     int n_features_out;     /* size of currentVOFeatures on return */
+    int lk_level_visits;    /* (feature, pass, level) visits of the four LK passes that reached the Newton loop */
+    int lk_newton_steps;    /* Newton iterations of the four LK passes (the work term of the LK flop model) */
 } svo_frame_stats;
 
 typedef struct svo_context svo_context;

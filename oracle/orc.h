@@ -196,7 +196,10 @@ typedef struct {
     int ransac_iters;
     int fail_reason;        /* 0 ok, 1 first frame, 2 too few tracks, 3 ransac fail / few inliers, 4 motion gate */
     int n_features_out;     /* size of currentVOFeatures when the callback returns */
+    int lk_level_visits;    /* (point, pass, level) visits of the frame's four LK passes that reached the Newton loop */
+    int lk_newton_steps;    /* Newton iterations of the frame's four LK passes */
 } orc_frame_stats;
+extern long long orc_lk_counters[4];   /* running totals: [0] level visits that reached the Newton loop, [1] Newton iterations, [2] all visits */
 
 orc_vo* orc_vo_create(const orc_config* cfg);
 void    orc_vo_destroy(orc_vo* vo);

@@ -148,6 +148,7 @@ static void lk_level(int cn, const orc_pyramid* const* Apl, const orc_pyramid* c
     /* points are independent (cv::parallel_for_ over points in calcOpticalFlowPyrLK): one patch buffer per thread */
 #pragma omp parallel
     {
+    long long cnt_visit = 0, cnt_step = 0, cnt_all = 0;                  /* per-thread, added to the globals once below */
     int16_t* Iw = (int16_t*)malloc(sizeof(int16_t) * (size_t)ww * wh * 3 * cn);
     int16_t* dIw = Iw + (size_t)ww * wh * cn;
     int x, y, j, pc;
@@ -159,8 +160,7 @@ static void lk_level(int cn, const orc_pyramid* const* Apl, const orc_pyramid* c
         else { npx = next_pts[2 * i] * 2.f; npy = next_pts[2 * i + 1] * 2.f; }
         next_pts[2 * i] = npx; next_pts[2 * i + 1] = npy;
 
-#pragma omp atomic
-        orc_lk_counters[2]++;
+        cnt_all++;
         ppx -= half_x; ppy -= half_y;
         int ipx = cv_floor_f(ppx), ipy = cv_floor_f(ppy);
         if (ipx < -ww || ipx >= colsI || ipy < -wh || ipy >= rowsI) {
@@ -196,8 +196,7 @@ static void lk_level(int cn, const orc_pyramid* const* Apl, const orc_pyramid* c
             continue;
         }
         D = 1.f / D;
-#pragma omp atomic
-        orc_lk_counters[0]++;
+        cnt_visit++;
         npx -= half_x; npy -= half_y;
         float pdx = 0.f, pdy = 0.f;
         for (j = 0; j < max_count; j++) {
@@ -206,8 +205,7 @@ static void lk_level(int cn, const orc_pyramid* const* Apl, const orc_pyramid* c
                 if (level == 0) status[i] = 0;
                 break;
             }
-#pragma omp atomic
-            orc_lk_counters[1]++;
+            cnt_step++;
             a = npx - inx; b = npy - iny;
             iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
             iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
@@ -243,6 +241,12 @@ static void lk_level(int cn, const orc_pyramid* const* Apl, const orc_pyramid* c
         }
     }
     free(Iw);
+#pragma omp atomic
+    orc_lk_counters[0] += cnt_visit;
+#pragma omp atomic
+    orc_lk_counters[1] += cnt_step;
+#pragma omp atomic
+    orc_lk_counters[2] += cnt_all;
     }
 }
 

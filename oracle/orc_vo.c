@@ -193,7 +193,11 @@ int orc_vo_stereo_callback_cn(orc_vo* vo, const uint8_t* left, const uint8_t* ri
         build_plane_pyramids(L1, w, h, cn, c, pl1p);                                 /* :200 */
         build_plane_pyramids(R1, w, h, cn, c, pr1p);                                 /* :201 */
         for (k = 0; k < cn; k++) { l0[k] = &vo->pyrL0[k]; r0[k] = &vo->pyrR0[k]; l1[k] = &pl1p[k]; r1[k] = &pr1p[k]; }
-        orc_circular_match_cn(cn, l0, r0, l1, r1, n, pl0, pl1, pr1, pr0, plc, ok, c);   /* :203-230 */
+        {
+            const long long v0 = orc_lk_counters[0], s0 = orc_lk_counters[1];       /* (one VisualOdometry at a time per process: test infrastructure) */
+            orc_circular_match_cn(cn, l0, r0, l1, r1, n, pl0, pl1, pr1, pr0, plc, ok, c);   /* :203-230 */
+            st->lk_level_visits = (int)(orc_lk_counters[0] - v0); st->lk_newton_steps = (int)(orc_lk_counters[1] - s0);
+        }
         for (k = 0; k < cn; k++) {
             orc_pyramid_free(&vo->pyrL0[k]); orc_pyramid_free(&vo->pyrR0[k]);
             vo->pyrL0[k] = pl1p[k]; vo->pyrR0[k] = pr1p[k];                          /* :231-232 */

@@ -52,7 +52,7 @@ class SvoConfig(C.Structure):
 class SvoFrameStats(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "n_after_detect", "second_pass", "n_into_lk", "n_after_circular", "n_after_bounds",
-        "n_inliers", "ransac_iters", "fail_reason", "n_features_out")]
+        "n_inliers", "ransac_iters", "fail_reason", "n_features_out", "lk_level_visits", "lk_newton_steps")]
 
     def as_dict(self):
         return {f[0]: getattr(self, f[0]) for f in self._fields_}

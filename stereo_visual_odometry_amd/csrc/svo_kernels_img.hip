@@ -27,7 +27,7 @@ __global__ void k_frame_begin(DevBuffers d) {
     s.do_second = 0; s.n_lk = 0; s.n_tracks = 0; s.n_circ = 0; s.n_inliers = 0; s.ok = 0;
     s.pnp_best = -1; s.pnp_iters = 0; s.pnp_good = 0;
     s.fail_reason = s.active ? 0 : 1;
-    svo_frame_stats z = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    svo_frame_stats z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     s.stats = z;
 }
 

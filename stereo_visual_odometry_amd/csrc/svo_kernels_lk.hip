@@ -271,7 +271,7 @@ __device__ __forceinline__ void load_pairs(const uint8_t* __restrict__ p, unsign
 template <int W, int G, int CN>
 __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, size_t pstride,
                         float px, float py, float& outx, float& outy, int& status, const LkCrit& crit,
-                        const LkSegs<LkLayout<W, G>::SPL>& sg) {
+                        const LkSegs<LkLayout<W, G>::SPL>& sg, int& n_visits, int& n_steps) {
     using LL = LkLayout<W, G>;
     constexpr int PPL = LL::PPL, EXT = LL::EXT, NS = LL::NS, NB = LL::NB, SPL = LL::SPL;
     constexpr int KS = SPL * CN;                                        // (plane, segment) pairs per lane
@@ -447,6 +447,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         // the 2^-20 scale of the mismatch sums is folded into 1/D once per level: scaling by a power of two commutes with
         // every rounding below (no overflow: |A12 b| < 2^52; no underflow: 1/D >= 2^-41), so the steps skip that multiply
         const float Dts = (1.f / Dt) * FLT_SCALE;
+        n_visits++;
         nx -= half; ny -= half;
         // Newton iterations.  The search window (two rows of packed byte pairs per segment) lives in registers and is
         // re-loaded only when the INTEGER window origin floor(n) changes; most iterations move the window by a fraction of
@@ -487,6 +488,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         // returns true when the track is finished at this level
         auto newton_step = [&](float fa, float fb) __attribute__((always_inline)) -> bool {
             lk_weights(fa, fb, w0, w1);
+            n_steps++;
             int pb1 = 0, pb2 = 0;
 #pragma unroll
             for (int kk = 0; kk < KS; kk++) {
@@ -699,6 +701,7 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mo
         int allst = 1;
         int inb = !((p0.x < 0) || (p0.y < 0) || (p0.y >= Hf) || (p0.x >= Wf));                        // vo.cpp:344-359, pointsLeftT0
         float2 cur = p0;
+        int n_visits = 0, n_steps = 0;                                 // svo_frame_stats.lk_level_visits / lk_newton_steps
         if (writer) d.pl0[o] = p0;
 #pragma unroll 1
         for (int pass = 0; pass < 4; pass++) {
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mo
             const uint8_t* Bq = pass == 0 ? L1 : pass == 1 ? R1 : pass == 2 ? R0 : L0;
             float2* out = pass == 0 ? d.pl1 : pass == 1 ? d.pr1 : pass == 2 ? d.pr0 : d.plc;
             float2 q; int st;
-            lk_pass<W, G, CN>(d.geom, A, Bq, (size_t)d.geom.pyr_bytes, cur.x, cur.y, q.x, q.y, st, crit, sg);
+            lk_pass<W, G, CN>(d.geom, A, Bq, (size_t)d.geom.pyr_bytes, cur.x, cur.y, q.x, q.y, st, crit, sg, n_visits, n_steps);
             allst &= (st != 0);
             if (pass < 3) inb &= !((q.x < 0) || (q.y < 0) || (q.y >= Hf) || (q.x >= Wf));          // pl1, pr1, pr0 (not the returned point)
             if (writer) out[o] = q;
@@ -717,6 +720,8 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mo
             float off = (ex < ey) ? ey : ex;
             int circ = allst && !(off > thr);                                               // vo.cpp:227-230
             d.okmask[o] = (uint8_t)(circ | (inb << 1));
+            atomicAdd(&s.stats.lk_level_visits, n_visits);
+            atomicAdd(&s.stats.lk_newton_steps, n_steps);
         }
     }
 }
@@ -735,8 +740,8 @@ __global__ __launch_bounds__(64) void k_lk_single(DevBuffers d, int slotA, int c
     for (int base = blockIdx.x * FPW; base < n; base += gridDim.x * FPW) {
         const int idx = base + slot;
         if (idx >= n) continue;
-        float2 p = prev[idx], q; int st;
-        lk_pass<W, G, 1>(d.geom, A, Bp, 0, p.x, p.y, q.x, q.y, st, crit, sg);
+        float2 p = prev[idx], q; int st, nv = 0, ns = 0;
+        lk_pass<W, G, 1>(d.geom, A, Bp, 0, p.x, p.y, q.x, q.y, st, crit, sg, nv, ns);
         if (threadIdx.x % G == 0) { next[idx] = q; status[idx] = (uint8_t)st; }
     }
 }

@@ -37,7 +37,13 @@ class StereoSequence:
     """
 
     def __init__(self, cal=KITTI00, n_frames=16, seed=0x5EED0002, step=0.5, yaw_amp_deg=0.2,
-                 depth=(22.0, 90.0), n_layers=6, cell_px=13.0, coverage=0.55, noise=1.0):
+                 depth=(22.0, 90.0), n_layers=6, cell_px=13.0, coverage=0.55, noise=1.0,
+                 movers=0.0, mover_step=(0.6, 0.15), mover_blob=4.0):
+        """movers > 0 adds an INDEPENDENTLY MOVING foreground layer covering that fraction of the pixels (blobs mover_blob texture
+        cells wide), at 0.8 x the nearest depth, sliding by mover_step metres per frame in world x / y (the default is 20 px per
+        frame at KITTI-00 focal length: beyond the 8 px reprojection threshold, so its tracks really are outliers).  Its features track
+        perfectly well through the four LK passes (left / right views of one instant agree) but contradict the camera motion,
+        i.e. they are the outliers RANSAC-PnP exists for — a static scene never makes the adaptive loop work."""
         self.cal, self.n_frames = dict(cal), n_frames
         rng = np.random.default_rng(seed)
         self.baseline = -cal["bf"] / cal["fx"]
@@ -50,6 +56,14 @@ class StereoSequence:
         self.mask[-1] = True
         self.mask_scale = 11.0                                           # mask cells = 11 texture cells
         self.aa_px, self.cell_px, self.noise = 1.5, cell_px, noise
+        self.movers, self.mover_step, self.mover_blob = float(movers), (float(mover_step[0]), float(mover_step[1])), float(mover_blob)
+        if self.movers > 0:                                              # drawn after everything else: movers = 0 renders the same bytes as before
+            mrng = np.random.default_rng(seed ^ 0x5A5A5A)
+            self.mover_z = 0.8 * depth[0]
+            self.mover_cell = self.mover_z * cell_px / cal["fx"]
+            self.mover_off = mrng.uniform(0, 256, 2)
+            self.mover_tex = mrng.integers(25, 231, (256, 256)).astype(np.float32)
+            self.mover_mask = mrng.random((64, 64)) < self.movers
         W, H = cal["width"], cal["height"]
         yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
         self._rx = (xx - cal["cx"]) / cal["fx"]
@@ -89,13 +103,26 @@ class StereoSequence:
         bot = T[j1, i0] * (1 - sx) + T[j1, i1] * sx
         return top * (1 - sy) + bot * sy
 
-    def _render_view(self, Rwc, C):
+    def _render_view(self, Rwc, C, k=0):
         H, W = self._rx.shape
         dx = Rwc[0, 0] * self._rx + Rwc[0, 1] * self._ry + Rwc[0, 2]
         dy = Rwc[1, 0] * self._rx + Rwc[1, 1] * self._ry + Rwc[1, 2]
         dz = Rwc[2, 0] * self._rx + Rwc[2, 1] * self._ry + Rwc[2, 2]
         img = np.zeros((H, W), np.float32)
         todo = np.ones((H, W), bool)
+        if self.movers > 0:                                              # the moving layer is nearest: it occludes the static scene
+            sm = (self.mover_z - C[2]) / dz
+            tx = ((C[0] + sm * dx - k * self.mover_step[0]) / self.mover_cell + self.mover_off[0]).astype(np.float32)
+            ty = ((C[1] + sm * dy - k * self.mover_step[1]) / self.mover_cell + self.mover_off[1]).astype(np.float32)
+            mi = np.floor(tx / self.mover_blob).astype(np.int64) & 63
+            mj = np.floor(ty / self.mover_blob).astype(np.int64) & 63
+            hit = self.mover_mask[mj, mi]
+            if hit.any():
+                keep_tex, keep_cell = self.tex, self.layer_cell
+                self.tex = np.concatenate([self.tex, self.mover_tex[None]])     # _layer_value reads self.tex[l]
+                img[hit] = self._layer_value(len(self.tex) - 1, tx[hit], ty[hit])
+                self.tex, self.layer_cell = keep_tex, keep_cell
+                todo &= ~hit
         for l, zl in enumerate(self.layer_z):
             s = (zl - C[2]) / dz
             tx = ((C[0] + s * dx) / self.layer_cell[l] + self.layer_off[l, 0]).astype(np.float32)
@@ -113,7 +140,7 @@ class StereoSequence:
         T = self.poses[k]
         Rwc, C = T[:3, :3], T[:3, 3]
         Cr = C + Rwc @ np.array([self.baseline, 0, 0])
-        return self._render_view(Rwc, C), self._render_view(Rwc, Cr)
+        return self._render_view(Rwc, C, k), self._render_view(Rwc, Cr, k)
 
     def depth_at(self, k, u, v):
         """Ground-truth depth (camera z) of left-image pixel(s) (u, v) in frame k."""

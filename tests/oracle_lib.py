@@ -11,7 +11,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
-_LIB_PATH = os.path.join(ORACLE_DIR, "libsvo_oracle.so")
+# SVO_ORACLE_LIB selects another build of the same sources (oracle/Makefile: `native` for the timed CPU baseline,
+# `asan` for the sanitizer run); the default is the portable -O2 checker
+_LIB_PATH = os.environ.get("SVO_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libsvo_oracle.so")
 
 
 def build_oracle(force=False):
@@ -36,7 +38,7 @@ class OrcConfig(C.Structure):
 class OrcFrameStats(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "n_after_detect", "second_pass", "n_into_lk", "n_after_circular", "n_after_bounds",
-        "n_inliers", "ransac_iters", "fail_reason", "n_features_out")]
+        "n_inliers", "ransac_iters", "fail_reason", "n_features_out", "lk_level_visits", "lk_newton_steps")]
 
 
 ORC_MAX_LEVELS = 8
