@@ -129,7 +129,7 @@ def main():
     # ---- workload: BASELINE.json configs[1] — KITTI-00 shaped 1241x376, ~2000 FAST features, LK 21x21, maxLevel 3
     win = int(os.environ.get("SVO_BENCH_WIN", "21"))
     WL = {   # calibration, scene parameters, config overrides, description
-        "cfg2": (syn.KITTI00, dict(seed=0x5EED0002, step=0.5, cell_px=float(os.environ.get("SVO_BENCH_CELL", "17.4"))), dict(max_level=3, ransac_iterations=100),
+        "cfg2": (syn.KITTI00, dict(seed=0x5EED0002, step=0.5, cell_px=float(os.environ.get("SVO_BENCH_CELL", "16.6"))), dict(max_level=3, ransac_iterations=100),
                  "BASELINE configs[1]: KITTI-00 calibration, 1241x376, LK 21x21 win, maxLevel 3, 100 RANSAC-PnP iterations"),
         "cfg3": (syn.KITTI00, dict(seed=0x5EED0003, step=0.5, cell_px=12.0), dict(max_level=4, ransac_iterations=1000),
                  "BASELINE configs[2]: KITTI-00 calibration, 1241x376, ~4000 features, LK 21x21 win, maxLevel 4, 1000 RANSAC-PnP iterations"),
