@@ -120,6 +120,11 @@ int svo_get_last_tracks(svo_context* ctx, int seq, int cap, float* pl0, float* p
                         float* world, uint8_t* inlier);
 /* Timing: HIP-event milliseconds of the dominant kernel (the fused LK chain) in the last processed frame, and of the whole frame. */
 int svo_get_last_timing(svo_context* ctx, float* lk_ms, float* frame_ms);
+/* Per-stage HIP-event milliseconds of the last collected frame (all sequences of the context together), in pipeline order:
+ * ms[0] ingest + pyramids (vo.cpp:74-75, 200-201)   ms[1] FAST + bucketing, both passes (vo.cpp:325-332)
+ * ms[2] the four LK passes + masks (vo.cpp:203-230, 341-359)   ms[3] compaction + triangulation (vo.cpp:233-238, 360-364, 89-94)
+ * ms[4] RANSAC-PnP, inlier update, gates, result record (vo.cpp:101-136).  The reference has no timers. */
+int svo_get_stage_timing(svo_context* ctx, float ms[5]);
 void* svo_get_stream(svo_context* ctx);   /* hipStream_t the context launches on */
 
 /* ------------------------------------------------------------------------------------------------

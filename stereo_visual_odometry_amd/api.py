@@ -299,6 +299,14 @@ class BatchVisualOdometry:
         check(lib.svo_get_last_timing(self._h, C.byref(lk), C.byref(fr)))
         return lk.value, fr.value
 
+    STAGES = ("ingest+pyramid", "detect", "lk", "compact+triangulate", "pnp")
+
+    def stage_timing(self):
+        """HIP-event milliseconds of the last collected frame per pipeline stage (svo_get_stage_timing) -> dict."""
+        ms = (C.c_float * 5)()
+        check(lib.svo_get_stage_timing(self._h, ms))
+        return dict(zip(self.STAGES, [float(x) for x in ms]))
+
     def stream(self):
         return lib.svo_get_stream(self._h)
 

@@ -6,6 +6,7 @@
 #include "svo_internal.hpp"
 #include <stdio.h>
 #include <string.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string>
 #include <vector>
@@ -69,6 +70,7 @@ struct svo_context {
     FrameResult* h_results = nullptr;            // pinned [SVO_RING][B]
     const uint8_t** h_ptrs = nullptr;            // pinned [SVO_RING][2][B]
     hipEvent_t ev_done[SVO_RING] = {}, ev_f0[SVO_RING] = {}, ev_lk0[SVO_RING] = {}, ev_lk1[SVO_RING] = {};
+    hipEvent_t ev_pyr[SVO_RING] = {}, ev_tri[SVO_RING] = {};   // stage boundaries: pyramids built / world points triangulated
     int head = 0, tail = 0, inflight = 0;        // ring indices: head = next to enqueue, tail = oldest outstanding
     int last_slot = -1;
     uint8_t* staging = nullptr;                  // device [2][B][W*H] for host-image calls
@@ -152,6 +154,7 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     for (int i = 0; i < SVO_RING; i++) {
         HIPCHK(hipEventCreate(&c->ev_done[i])); HIPCHK(hipEventCreate(&c->ev_f0[i]));
         HIPCHK(hipEventCreate(&c->ev_lk0[i])); HIPCHK(hipEventCreate(&c->ev_lk1[i]));
+        HIPCHK(hipEventCreate(&c->ev_pyr[i])); HIPCHK(hipEventCreate(&c->ev_tri[i]));
     }
     // initial state: rotation = I, translation = 0, last_transform = I (vo.h:266-268); no slots in use
     std::vector<SeqState> hs(B);
@@ -187,6 +190,8 @@ extern "C" void svo_destroy(svo_context* c) {
         if (c->ev_f0[i]) (void)hipEventDestroy(c->ev_f0[i]);
         if (c->ev_lk0[i]) (void)hipEventDestroy(c->ev_lk0[i]);
         if (c->ev_lk1[i]) (void)hipEventDestroy(c->ev_lk1[i]);
+        if (c->ev_pyr[i]) (void)hipEventDestroy(c->ev_pyr[i]);
+        if (c->ev_tri[i]) (void)hipEventDestroy(c->ev_tri[i]);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -199,14 +204,19 @@ extern "C" int svo_set_projection(svo_context* c, int seq, const float Pl[12], c
     if (seq < -1 || seq >= c->d.B) return fail_arg("seq out of range");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    float K[9];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) K[3 * i + j] = Pl[4 * i + j];      // vo.cpp:16-25
-    for (int s = (seq < 0 ? 0 : seq); s < (seq < 0 ? c->d.B : seq + 1); s++) {
-        SeqState* ds = c->d.st + s;
-        HIPCHK(hipMemcpy(&ds->Pl, Pl, sizeof(float) * 12, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(&ds->Pr, Pr, sizeof(float) * 12, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(&ds->K, K, sizeof(float) * 9, hipMemcpyHostToDevice));
+    // Pl, Pr, K are adjacent members of SeqState: one strided 2-D copy writes them into every selected sequence's record
+    // (row = the 33 floats, pitch = sizeof(SeqState)) instead of three blocking copies per sequence
+    static_assert(offsetof(SeqState, Pr) == offsetof(SeqState, Pl) + sizeof(float) * 12 && offsetof(SeqState, K) == offsetof(SeqState, Pl) + sizeof(float) * 24,
+                  "Pl, Pr, K must be contiguous");
+    const int s0 = seq < 0 ? 0 : seq, ns = seq < 0 ? c->d.B : 1;
+    std::vector<float> rows((size_t)ns * 33);
+    for (int s = 0; s < ns; s++) {
+        float* r = rows.data() + (size_t)s * 33;
+        memcpy(r, Pl, sizeof(float) * 12); memcpy(r + 12, Pr, sizeof(float) * 12);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[24 + 3 * i + j] = Pl[4 * i + j];   // K = Pl[:, :3]  (vo.cpp:16-25)
     }
+    HIPCHK(hipMemcpy2D((char*)(c->d.st + s0) + offsetof(SeqState, Pl), sizeof(SeqState), rows.data(), sizeof(float) * 33, sizeof(float) * 33, (size_t)ns,
+                       hipMemcpyHostToDevice));
     c->projection_set = true;
     return SVO_OK;
 }
@@ -225,6 +235,7 @@ static int enqueue_frame(svo_context* c, const uint8_t* const* left_dev, const u
     launch_frame_begin(d, s);
     launch_ingest(d, dp, stride, s);
     launch_pyramid(d, s);
+    HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
     launch_detect(d, 0, -1, s);
     launch_detect(d, 1, -1, s);
     HIPCHK(hipEventRecord(c->ev_lk0[slot], s));
@@ -237,6 +248,7 @@ static int enqueue_frame(svo_context* c, const uint8_t* const* left_dev, const u
     HIPCHK(hipEventRecord(c->ev_lk1[slot], s));
     launch_compact(d, s);
     launch_triangulate(d, s);
+    HIPCHK(hipEventRecord(c->ev_tri[slot], s));
     launch_pnp(d, s);
     launch_frame_end(d, slot, s);
     HIPCHK(hipMemcpyAsync(c->h_results + (size_t)slot * B, d.results + (size_t)slot * B, sizeof(FrameResult) * B, hipMemcpyDeviceToHost, s));
@@ -328,6 +340,15 @@ extern "C" int svo_get_last_timing(svo_context* c, float* lk_ms, float* frame_ms
     const int s = c->last_slot;
     if (lk_ms) HIPCHK(hipEventElapsedTime(lk_ms, c->ev_lk0[s], c->ev_lk1[s]));
     if (frame_ms) HIPCHK(hipEventElapsedTime(frame_ms, c->ev_f0[s], c->ev_done[s]));
+    return SVO_OK;
+}
+
+extern "C" int svo_get_stage_timing(svo_context* c, float ms[5]) {
+    if (!c || !ms || c->last_slot < 0) return fail_arg("no frame collected yet");
+    HIPCHK(hipSetDevice(c->device));
+    const int s = c->last_slot;
+    hipEvent_t ev[6] = {c->ev_f0[s], c->ev_pyr[s], c->ev_lk0[s], c->ev_lk1[s], c->ev_tri[s], c->ev_done[s]};
+    for (int i = 0; i < 5; i++) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
     return SVO_OK;
 }
 
