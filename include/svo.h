@@ -107,6 +107,15 @@ int svo_process_batch(svo_context* ctx, const uint8_t* const* left, const uint8_
  * Returns 1 (pose produced), 0 (no pose this frame; T_out = last good transform) or a negative svo_status. */
 int svo_process(svo_context* ctx, const uint8_t* left, const uint8_t* right, int stride, double T_out[16], svo_frame_stats* stats);
 
+/* replaces: VisualOdometry::circularMatching(imgLeftT1, imgRightT1, pointsLeftT0, pointsRightT0, pointsLeftT1, pointsRightT1, features)
+ * (vo.h:374-379, vo.cpp:169-240) as the MEMBER call it is in the reference: the T0 side is the pyramid pair this context
+ * cached in its last svo_process / svo_circular_matching (vo.h:257-258; prime it with svo_process, as main.cpp:191 does), the
+ * pyramids of the given T1 images become the cached pair (vo.cpp:231-232) — the next svo_process tracks against them.
+ * Without the compaction: n points in, n points out per list, ok[n] = all four LK statuses && loop closure (vo.cpp:217-230).
+ * n == 0 returns before anything is cached (vo.cpp:179-181).  n_seq == 1 contexts; images in the context's format. */
+int svo_circular_matching(svo_context* ctx, const uint8_t* left_t1, const uint8_t* right_t1, int stride, int n,
+                          const float* pl0, float* pl1, float* pr1, float* pr0, float* pl0_circle, uint8_t* ok);
+
 /* Asynchronous form for throughput: enqueue one frame for every sequence and return immediately
  * (device pointers only; the images must stay valid until the matching svo_collect).
  * Results are queued in order; svo_collect blocks for the oldest outstanding frame. At most 8 in flight. */

@@ -13,6 +13,7 @@
 // partner was lost); messages older than the chosen partner are dropped.  Queues are bounded (default 10): on
 // overflow the oldest message is dropped, as message_filters does.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <deque>
 #include <functional>

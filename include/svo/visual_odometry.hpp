@@ -182,12 +182,13 @@ class VisualOdometry {                                               // include/
         if (!ctx_) {                                                  // the reference learns size and type from the first frame
             cfg_.channels = image_left.channels;
             svo_throw(svo_create(&cfg_, default_device(), 1, image_left.cols, image_left.rows, &ctx_));
+            width_ = image_left.cols; height_ = image_left.rows;
             // like the reference, a first frame needs no projection matrices (vo.cpp:47-56 only caches); until
             // initalize_projection_matricies is called they are all-zero, as the reference's empty Mats effectively are
             if (!have_p_) { leftCameraProjection_.fill(0.f); rightCameraProjection_.fill(0.f); }
             svo_throw(svo_set_projection(ctx_, -1, leftCameraProjection_.data(), rightCameraProjection_.data()));
         }
-        if (image_left.channels == 1) remember(image_left, image_right);    // the T0 side of a later circularMatching call
+        check_frame(image_left, "left"); check_frame(image_right, "right");
         Mat44 T;
         int rc = svo_process(ctx_, image_left.data, image_right.data, image_left.step, T.data(), &stats);
         svo_throw(rc);
@@ -195,25 +196,22 @@ class VisualOdometry {                                               // include/
     }
     // vo.h:374-379, vo.cpp:169-240.  Tracks pointsLeftT0 around the loop T0-left -> T1-left -> T1-right -> T0-right -> T0-left,
     // removes every point (and its feature) that lost an LK status or does not close the loop within 0.15 px, and makes the
-    // T1 images the new "last" ones (the reference caches their pyramids, :231-232; on empty input it returns before doing
-    // so, :179-181).  The T0 side is the image pair of the previous stereo_callback / circularMatching, as in the reference,
-    // which keeps their pyramids.  Single-channel images.  Differences: the facade keeps host copies of that pair for this
-    // entry point and does not touch the device-resident state stereo_callback works on.
+    // T1 pyramids the cached pair (vo.cpp:231-232; on empty input it returns before doing so, :179-181).  As in the
+    // reference this is a member call on the SAME state stereo_callback works on: the T0 side is the pyramid pair cached on
+    // the device by the previous stereo_callback / circularMatching (prime it with stereo_callback, as main.cpp:191 does), and
+    // the next stereo_callback tracks against the pair cached here.
     void circularMatching(const Image& imgLeftT1, const Image& imgRightT1, std::vector<Point2f>& pointsLeftT0,
                           std::vector<Point2f>& pointsRightT0, std::vector<Point2f>& pointsLeftT1,
                           std::vector<Point2f>& pointsRightT1, FeatureSet& current_features) {
         if (pointsLeftT0.empty()) return;                                                          // vo.cpp:179-181
-        if (last_left_.empty()) throw std::runtime_error("circularMatching: no previous frame (call stereo_callback first)");
-        if (imgLeftT1.channels != 1 || imgRightT1.channels != 1) throw std::runtime_error("circularMatching: single-channel images");
-        const int n = (int)pointsLeftT0.size(), w = imgLeftT1.cols, h = imgLeftT1.rows;
-        if (w != last_w_ || h != last_h_) throw std::runtime_error("circularMatching: image size changed");
+        if (!ctx_) throw std::runtime_error("circularMatching: no cached pyramids (call stereo_callback first)");
+        check_frame(imgLeftT1, "left"); check_frame(imgRightT1, "right");
+        const int n = (int)pointsLeftT0.size();
         std::vector<Point2f> loop(n);
         std::vector<uint8_t> ok(n);
         pointsLeftT1.resize(n); pointsRightT1.resize(n); pointsRightT0.resize(n);
-        const std::vector<uint8_t> l1 = pack(imgLeftT1), r1 = pack(imgRightT1);
-        svo_throw(svo_circular_match(default_device(), &cfg_, last_left_.data(), last_right_.data(), l1.data(), r1.data(), w, h, w, n,
-                                     &pointsLeftT0[0].x, &pointsLeftT1[0].x, &pointsRightT1[0].x, &pointsRightT0[0].x, &loop[0].x, ok.data()));
-        last_left_ = l1; last_right_ = r1;                                                          // vo.cpp:231-232
+        svo_throw(svo_circular_matching(ctx_, imgLeftT1.data, imgRightT1.data, imgLeftT1.step, n, &pointsLeftT0[0].x, &pointsLeftT1[0].x,
+                                        &pointsRightT1[0].x, &pointsRightT0[0].x, &loop[0].x, ok.data()));
         const std::vector<bool> keep(ok.begin(), ok.end());
         deleteFeaturesWithFailureStatus(current_features, keep);                                    // vo.cpp:233
         deletePointsWithFailureStatus(pointsLeftT0, keep); deletePointsWithFailureStatus(pointsLeftT1, keep);   // :234-238
@@ -222,7 +220,8 @@ class VisualOdometry {                                               // include/
 
     // vo.h:354-362, vo.cpp:315-366: detect on imageLeftT0 (second pass at threshold / 4 if fewer than 100 features), track the
     // feature set through circularMatching, then drop everything that left the image in any of the four views.
-    // imageLeftT0 / imageRightT0 also become the T0 side of the loop (in stereo_callback they are the cached pair anyway).
+    // As in the reference, imageLeftT0 is only what FAST runs on (vo.cpp:325); the loop's T0 side is the cached pyramid pair
+    // (imageRightT0 is not read at all, vo.cpp:315-366), so the caller primes the object with stereo_callback(imageLeftT0, imageRightT0).
     void matchingFeatures(const Image& imageLeftT0, const Image& imageRightT0, const Image& imageLeftT1, const Image& imageRightT1,
                           FeatureSet& currentVOFeatures, std::vector<Point2f>& pointsLeftT0, std::vector<Point2f>& pointsRightT0,
                           std::vector<Point2f>& pointsLeftT1, std::vector<Point2f>& pointsRightT1) {
@@ -230,7 +229,7 @@ class VisualOdometry {                                               // include/
         if (currentVOFeatures.size() < PRE_MATCHING_FEATURE_THRESHOLD)                              // :327-332
             currentVOFeatures.appendFeaturesFromImage(imageLeftT0, FAST_THRESHOLD / 4);
         pointsLeftT0 = currentVOFeatures.points;                                                    // :338
-        remember(imageLeftT0, imageRightT0);
+        (void)imageRightT0;
         circularMatching(imageLeftT1, imageRightT1, pointsLeftT0, pointsRightT0, pointsLeftT1, pointsRightT1, currentVOFeatures);
         std::vector<bool> inside(pointsLeftT0.size());                                              // :341-359
         for (size_t i = 0; i < inside.size(); i++) {
@@ -251,17 +250,17 @@ class VisualOdometry {                                               // include/
     svo_context* handle() { return ctx_; }
 
    private:
-    static std::vector<uint8_t> pack(const Image& im) {              // contiguous single-channel copy
-        std::vector<uint8_t> v((size_t)im.rows * im.cols);
-        for (int y = 0; y < im.rows; y++) std::memcpy(&v[(size_t)y * im.cols], im.data + (size_t)y * im.step, (size_t)im.cols);
-        return v;
+    // cv::Mat carries its own size and type and OpenCV asserts on mismatches; raw pointers do not, so the facade checks every
+    // frame against the context (a shorter or narrower buffer would be read past its end)
+    void check_frame(const Image& im, const char* which) const {
+        if (im.empty()) throw std::runtime_error(std::string(which) + " image is empty");
+        if (im.cols != width_ || im.rows != height_ || im.channels != cfg_.channels || im.step < im.cols * im.channels)
+            throw std::runtime_error(std::string(which) + " image does not match the size / channels of the first frame");
     }
-    void remember(const Image& l, const Image& r) { last_left_ = pack(l); last_right_ = pack(r); last_w_ = l.cols; last_h_ = l.rows; }
     svo_config cfg_;
     svo_context* ctx_ = nullptr;
     bool have_p_ = false;
-    std::vector<uint8_t> last_left_, last_right_;                     // imageLeftT0_ / imageRightT0_ for circularMatching (vo.h:239)
-    int last_w_ = 0, last_h_ = 0;
+    int width_ = 0, height_ = 0;                                      // learnt from the first frame
 };
 
 }   // namespace visual_odometry

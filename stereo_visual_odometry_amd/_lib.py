@@ -65,7 +65,7 @@ lib.svo_get_stream.argtypes = [C.c_void_p]
 # every symbol include/svo.h declares (tests/test_abi.py checks the list against the header)
 EXPORTS = [
     "svo_last_error", "svo_device_count", "svo_config_default", "svo_create", "svo_destroy", "svo_set_projection",
-    "svo_process_batch", "svo_process", "svo_submit_batch", "svo_collect", "svo_get_features", "svo_get_last_tracks",
+    "svo_process_batch", "svo_process", "svo_circular_matching", "svo_submit_batch", "svo_collect", "svo_get_features", "svo_get_last_tracks",
     "svo_get_last_timing", "svo_get_stage_timing", "svo_get_stream", "svo_fast_detect", "svo_fast_score_map", "svo_bucket_filter",
     "svo_append_features_from_image", "svo_build_pyramid", "svo_lk_track", "svo_circular_match",
     "svo_find_close_points", "svo_triangulate", "svo_camera_to_world", "svo_inverse_transform",
@@ -89,6 +89,12 @@ def default_config(**over):
         if not hasattr(c, k):
             raise AttributeError(k)
         setattr(c, k, v)
+    return c
+
+
+def copy_config(cfg):
+    c = SvoConfig()
+    C.memmove(C.byref(c), C.byref(cfg), C.sizeof(SvoConfig))
     return c
 
 

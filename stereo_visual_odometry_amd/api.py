@@ -78,8 +78,9 @@ def findClosePoints(points_1, points_2, threshold, device=0):
 
 def cameraToWorld(cameraProjection, cameraPoints, worldPoints, rotation, translation,
                   iterations=RANSAC_ITERATIONS, reprojection_error=RANSAC_REPROJECTION_ERROR, confidence=0.98, device=0):
-    """vo.h:452-456 — returns ((inliers, success), rotation, translation); rotation/translation are
-    the updated values on success and the inputs on failure (vo.cpp:307-311)."""
+    """vo.h:452-456 — returns ((inliers, success), rotation, translation, iterations_run): the reference's pair, then its two
+    in/out arguments (the updated values on success, the inputs on failure, vo.cpp:307-311), then how many RANSAC iterations
+    the adaptive loop ran (a counter the reference does not expose)."""
     K = np.ascontiguousarray(cameraProjection, np.float32).reshape(-1)[:9].copy() if np.size(cameraProjection) == 9 else \
         np.ascontiguousarray(np.asarray(cameraProjection, np.float32)[:3, :3]).reshape(9)
     cam = _pts(cameraPoints)
@@ -345,37 +346,46 @@ class VisualOdometry(BatchVisualOdometry):
         L, R = u8frame(image_left), u8frame(image_right)
         if not self._created:                         # the reference learns the image size (and type) from the first frame
             cfg, device = self._args
-            if L.ndim == 3:                           # colour Mats, as the reference CLI feeds them (main.cpp:38-46)
-                cfg = cfg if cfg is not None else default_config()
-                cfg.channels = 3
+            cfg = _lib.copy_config(cfg) if cfg is not None else default_config()       # never write into the caller's struct
+            cfg.channels = 3 if L.ndim == 3 else 1    # colour Mats, as the reference CLI feeds them (main.cpp:38-46)
             super().__init__(L.shape[1], L.shape[0], 1, cfg, device)
             self._created = True
             # like the reference, a first frame needs no projection matrices (vo.cpp:47-56 only caches); until
             # initalize_projection_matricies is called they are all-zero, as the reference's empty Mats effectively are
             super().initalize_projection_matricies(*(self._P if self._P is not None else (np.zeros(12, np.float32), np.zeros(12, np.float32))))
-        if L.ndim == 2:
-            self._last = (L.copy(), R.copy())         # the T0 side of a later circularMatching call (vo.h:239)
+        self._check_frame(L, "left"); self._check_frame(R, "right")
         T = np.zeros(16)
         st = SvoFrameStats()
         rc = check(lib.svo_process(self._h, ptr(L), ptr(R), L.strides[0], ptr(T), C.byref(st)))
         self.stats = st
         return bool(rc), T.reshape(4, 4)
 
+    def _check_frame(self, img, which):
+        """cv::Mat carries size and type and OpenCV asserts on a mismatch; a raw pointer does not: check before the C call."""
+        want = (self.height, self.width) + ((3,) if self.cfg.channels == 3 else ())
+        if img.shape != want:
+            raise ValueError("%s image has shape %s, the context was created for %s" % (which, img.shape, want))
+
     def circularMatching(self, imgLeftT1, imgRightT1, pointsLeftT0, current_features):
         """vo.h:374-379, vo.cpp:169-240.  Tracks pointsLeftT0 around T0-left -> T1-left -> T1-right -> T0-right -> T0-left against
-        the image pair of the previous stereo_callback / circularMatching, removes every point (and its feature, in place)
-        that lost an LK status or does not close the loop, makes the T1 pair the new "last" one.
+        the pyramid pair this object cached on the device in its previous stereo_callback / circularMatching, removes every point
+        (and its feature, in place) that lost an LK status or does not close the loop, and makes the T1 pyramids the cached pair
+        (vo.cpp:231-232) — the state stereo_callback itself works on, as in the reference.
         Returns (pointsLeftT0, pointsRightT0, pointsLeftT1, pointsRightT1) — Python has no out-parameters."""
         p0 = _pts(pointsLeftT0)
         empty = np.zeros((0, 2), np.float32)
         if len(p0) == 0:
             return p0, empty, empty, empty                                                  # vo.cpp:179-181
-        if getattr(self, "_last", None) is None:
-            raise RuntimeError("circularMatching: no previous frame (call stereo_callback first)")
-        l1, r1 = u8img(imgLeftT1), u8img(imgRightT1)
-        cfg = self.cfg if getattr(self, "cfg", None) is not None else (self._args[0] or default_config())
-        pl1, pr1, pr0, _, ok = circularMatching(cfg, self._last[0], self._last[1], l1, r1, p0, self._args[1])
-        self._last = (l1.copy(), r1.copy())                                                 # vo.cpp:231-232
+        if not self._created:
+            raise RuntimeError("circularMatching: no cached pyramids (call stereo_callback first)")
+        l1, r1 = u8frame(imgLeftT1), u8frame(imgRightT1)
+        self._check_frame(l1, "left"); self._check_frame(r1, "right")
+        n = len(p0)
+        outs = [np.zeros((n, 2), np.float32) for _ in range(4)]
+        ok = np.zeros(n, np.uint8)
+        check(lib.svo_circular_matching(self._h, ptr(l1), ptr(r1), l1.strides[0], n, ptr(p0), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]),
+                                        ptr(outs[3]), ptr(ok)))
+        pl1, pr1, pr0 = outs[0], outs[1], outs[2]
         keep = ok.astype(bool)
         deleteFeaturesWithFailureStatus(current_features, keep)                             # :233
         return p0[keep], pr0[keep], pl1[keep], pr1[keep]                                    # :234-238
@@ -385,9 +395,9 @@ class VisualOdometry(BatchVisualOdometry):
         currentVOFeatures.appendFeaturesFromImage(imageLeftT0, FAST_THRESHOLD)              # :325
         if currentVOFeatures.size() < PRE_MATCHING_FEATURE_THRESHOLD:                       # :327-332
             currentVOFeatures.appendFeaturesFromImage(imageLeftT0, FAST_THRESHOLD // 4)
-        self._last = (u8img(imageLeftT0).copy(), u8img(imageRightT0).copy())
+        # as in the reference, imageLeftT0 only feeds FAST; the loop's T0 side is the cached pyramid pair (prime with stereo_callback)
         pl0, pr0, pl1, pr1 = self.circularMatching(imageLeftT1, imageRightT1, currentVOFeatures.points.copy(), currentVOFeatures)
-        h, w = u8img(imageLeftT1).shape
+        h, w = u8frame(imageLeftT1).shape[:2]
         inside = np.ones(len(pl0), bool)                                                    # :341-359
         for q in (pl0, pl1, pr0, pr1):
             inside &= ~((q[:, 0] < 0) | (q[:, 1] < 0) | (q[:, 1] >= h) | (q[:, 0] >= w))

@@ -221,6 +221,9 @@ extern "C" int svo_set_projection(svo_context* c, int seq, const float Pl[12], c
     return SVO_OK;
 }
 
+static int stage_host_images(svo_context* c, const uint8_t* const* left, const uint8_t* const* right, int stride,
+                             std::vector<const uint8_t*>& lp, std::vector<const uint8_t*>& rp);
+
 // Enqueue one frame for all sequences.  ptrs: host array [2][B] of DEVICE image pointers.
 static int enqueue_frame(svo_context* c, const uint8_t* const* left_dev, const uint8_t* const* right_dev, int stride) {
     if (c->inflight >= SVO_RING) { g_err = "too many frames in flight (collect first)"; return SVO_ERR_STATE; }
@@ -299,26 +302,15 @@ extern "C" int svo_process_batch(svo_context* c, const uint8_t* const* left, con
     if (stride < c->d.geom.W * c->d.CN) return fail_arg("stride < width * channels");
     if (c->inflight != 0) { g_err = "svo_process_batch with frames in flight"; return SVO_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
-    const int B = c->d.B, W = c->d.geom.W, H = c->d.geom.H;
+    const int W = c->d.geom.W;
     int rc;
     if (images_on_device) {
         rc = enqueue_frame(c, left, right, stride);
     } else {
         // the caller's buffers are only borrowed for the duration of the call: copy to the device first (SURVEY.md §8b "Ownership")
-        const size_t rowb = (size_t)W * c->d.CN, img = rowb * H;
-        if (!c->staging) HIPCHK(hipMalloc((void**)&c->staging, img * 2 * B));
-        if (!c->h_staging) HIPCHK(hipHostMalloc((void**)&c->h_staging, img * 2 * B));
-        // rows are packed into pinned memory on the CPU (handles any stride), then ONE contiguous async H2D copy
-        // (a 2-D copy from pageable memory degenerates into per-row transfers: 3.5 ms per 1241x376 image)
-        std::vector<const uint8_t*> lp(B), rp(B);
-        for (int i = 0; i < B; i++) {
-            if (!left[i] || !right[i]) return fail_arg("null image pointer");
-            uint8_t* hl = c->h_staging + img * i; uint8_t* hr = c->h_staging + img * (B + i);
-            if ((size_t)stride == rowb) { memcpy(hl, left[i], img); memcpy(hr, right[i], img); }
-            else for (int y = 0; y < H; y++) { memcpy(hl + (size_t)y * rowb, left[i] + (size_t)y * stride, rowb); memcpy(hr + (size_t)y * rowb, right[i] + (size_t)y * stride, rowb); }
-            lp[i] = c->staging + img * i; rp[i] = c->staging + img * (B + i);
-        }
-        HIPCHK(hipMemcpyAsync(c->staging, c->h_staging, img * 2 * B, hipMemcpyHostToDevice, c->stream));
+        const size_t rowb = (size_t)W * c->d.CN;
+        std::vector<const uint8_t*> lp, rp;
+        if ((rc = stage_host_images(c, left, right, stride, lp, rp)) != SVO_OK) return rc;
         rc = enqueue_frame(c, lp.data(), rp.data(), (int)rowb);
     }
     if (rc != SVO_OK) return rc;
@@ -332,6 +324,75 @@ extern "C" int svo_process(svo_context* c, const uint8_t* left, const uint8_t* r
     const uint8_t* l[1] = {left}; const uint8_t* r[1] = {right};
     int rc = svo_process_batch(c, l, r, stride, 0, T_out, &ok, stats);
     return rc != SVO_OK ? rc : ok;
+}
+
+// Host images -> pinned staging -> device staging (one contiguous H2D copy); fills lp / rp with the device addresses.
+static int stage_host_images(svo_context* c, const uint8_t* const* left, const uint8_t* const* right, int stride,
+                             std::vector<const uint8_t*>& lp, std::vector<const uint8_t*>& rp) {
+    const int B = c->d.B, W = c->d.geom.W, H = c->d.geom.H;
+    const size_t rowb = (size_t)W * c->d.CN, img = rowb * H;
+    if (!c->staging) HIPCHK(hipMalloc((void**)&c->staging, img * 2 * B));
+    if (!c->h_staging) HIPCHK(hipHostMalloc((void**)&c->h_staging, img * 2 * B));
+    // rows are packed into pinned memory on the CPU (handles any stride), then ONE contiguous async H2D copy
+    // (a 2-D copy from pageable memory degenerates into per-row transfers: 3.5 ms per 1241x376 image)
+    lp.resize(B); rp.resize(B);
+    for (int i = 0; i < B; i++) {
+        if (!left[i] || !right[i]) return fail_arg("null image pointer");
+        uint8_t* hl = c->h_staging + img * i; uint8_t* hr = c->h_staging + img * (B + i);
+        if ((size_t)stride == rowb) { memcpy(hl, left[i], img); memcpy(hr, right[i], img); }
+        else for (int y = 0; y < H; y++) { memcpy(hl + (size_t)y * rowb, left[i] + (size_t)y * stride, rowb); memcpy(hr + (size_t)y * rowb, right[i] + (size_t)y * stride, rowb); }
+        lp[i] = c->staging + img * i; rp[i] = c->staging + img * (B + i);
+    }
+    HIPCHK(hipMemcpyAsync(c->staging, c->h_staging, img * 2 * B, hipMemcpyHostToDevice, c->stream));
+    return SVO_OK;
+}
+
+static int read_state(svo_context* c, int seq, SeqState* hs);
+static int set_state(svo_context* c, const SeqState& hs);
+
+// VisualOdometry::circularMatching as a member call on the context's own state (vo.h:374-379, vo.cpp:169-240 without the
+// compaction): the T0 side is the pyramid pair the context cached (lastLeftPyramid / lastRightPyramid, vo.h:257-258), the
+// T1 pyramids are built from the given images and BECOME the cached pair (vo.cpp:231-232) — so the next stereo_callback
+// tracks against them, exactly as in the reference, where both entry points share those members.  Empty input returns
+// before anything is cached (vo.cpp:179-181).  currentVOFeatures, the cached T0 images and frame_id are left alone.
+extern "C" int svo_circular_matching(svo_context* c, const uint8_t* left_t1, const uint8_t* right_t1, int stride, int n,
+                                     const float* pl0, float* pl1, float* pr1, float* pr0, float* pl0_circle, uint8_t* ok) {
+    if (!c || !left_t1 || !right_t1 || n < 0) return fail_arg("bad arguments");
+    if (n > 0 && (!pl0 || !pl1 || !pr1 || !pr0 || !pl0_circle || !ok)) return fail_arg("null arrays");
+    if (c->d.B != 1) return fail_arg("svo_circular_matching needs a context created with n_seq == 1");
+    if (stride < c->d.geom.W * c->d.CN) return fail_arg("stride < width * channels");
+    if (c->inflight != 0) { g_err = "svo_circular_matching with frames in flight"; return SVO_ERR_STATE; }
+    if (n == 0) return SVO_OK;                                                    // vo.cpp:179-181
+    if (n > c->d.CAP) { g_err = "more points than the context's feature capacity"; return SVO_ERR_CAPACITY; }
+    HIPCHK(hipSetDevice(c->device));
+    SeqState hs; int rc = read_state(c, 0, &hs); if (rc != SVO_OK) return rc;
+    if (hs.frame_id < 1 || hs.slot_pyr_t0 < 0) { g_err = "no cached pyramids: call svo_process first (the reference primes them in stereo_callback, vo.cpp:47-56)"; return SVO_ERR_STATE; }
+    const SeqState keep = hs;
+    int t1 = 0;
+    for (int k = 0; k < 3; k++) if (k != hs.slot_img_t0 && k != hs.slot_pyr_t0) { t1 = k; break; }
+    // the points go into the idle half of the feature double-buffer (scratch between frames); the state is put back below
+    hs.slot_t1 = t1; hs.active = 1; hs.feat_buf = keep.feat_buf ^ 1; hs.n_feat = n;
+    HIPCHK(hipMemcpyAsync(c->d.feat_xy[hs.feat_buf], pl0, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    if ((rc = set_state(c, hs)) != SVO_OK) return rc;
+    std::vector<const uint8_t*> lp, rp;
+    const uint8_t* l[1] = {left_t1}; const uint8_t* r[1] = {right_t1};
+    if ((rc = stage_host_images(c, l, r, stride, lp, rp)) != SVO_OK) return rc;
+    const uint8_t** hp = c->h_ptrs; hp[0] = lp[0]; hp[1] = rp[0];
+    HIPCHK(hipMemcpyAsync((void*)c->d.img_ptrs, (const void*)hp, sizeof(uint8_t*) * 2, hipMemcpyHostToDevice, c->stream));
+    launch_ingest(c->d, c->d.img_ptrs, c->d.geom.W * c->d.CN, c->stream);
+    launch_pyramid(c->d, c->stream);                                              // vo.cpp:200-201
+    launch_lk_chain(c->d, n, c->stream);                                          // vo.cpp:203-230
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(pl1, c->d.pl1, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(pr1, c->d.pr1, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(pr0, c->d.pr0, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(pl0_circle, c->d.plc, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(ok, c->d.okmask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) ok[i] &= 1;                                       // bit0 = status0..3 && loop closure (vo.cpp:227-230)
+    SeqState out = keep;
+    out.slot_pyr_t0 = t1;                                                         // lastLeftPyramid = pyramidl1 (vo.cpp:231-232)
+    return set_state(c, out);
 }
 
 extern "C" int svo_get_last_timing(svo_context* c, float* lk_ms, float* frame_ms) {

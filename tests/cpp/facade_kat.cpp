@@ -110,6 +110,22 @@ static void test_circularMatching() {                                // main.cpp
     const size_t n_points = fs2.points.size();
     CHECK(pl0.size() == n_points && pl1.size() == n_points && pr0.size() == n_points && pr1.size() == n_points);
     CHECK(n_points == 121);
+    // circularMatching and stereo_callback share the cached pyramids (vo.cpp:231-232 -> the next :203): after the calls above the
+    // cached pair is (l1, r1), so a stereo_callback(l1, r1) tracks L1 -> L1 and sees NO motion, while an object that never
+    // called circularMatching tracks L0 -> L1 and sees the +1 px shift
+    Mat34f Pl = {322.11376f, 0, 327.47336f, 0, 0, 322.11376f, 176.33722f, 0, 0, 0, 1, 0}; Mat34f Pr = Pl; Pr[3] = -22.5428f;
+    vo.initalize_projection_matricies(Pl, Pr);
+    vo.stereo_callback(l1.view(), r1.view());
+    VisualOdometry fresh(Pl, Pr);
+    fresh.stereo_callback(l0.view(), r0.view()); fresh.stereo_callback(l1.view(), r1.view());
+    CHECK(vo.stats.n_after_bounds == 121 && fresh.stats.n_after_bounds == 121);
+    std::vector<Point2f> a0(121), a1(121), b0(121), b1(121);
+    CHECK(svo_get_last_tracks(vo.handle(), 0, 121, &a0[0].x, nullptr, &a1[0].x, nullptr, nullptr, nullptr) == 121);
+    CHECK(svo_get_last_tracks(fresh.handle(), 0, 121, &b0[0].x, nullptr, &b1[0].x, nullptr, nullptr, nullptr) == 121);
+    for (int i = 0; i < 121; i++) {
+        CHECK(std::fabs(a1[i].x - a0[i].x) < 0.05f && std::fabs(a1[i].y - a0[i].y) < 0.05f);
+        CHECK(std::fabs(b1[i].x - b0[i].x - 1) < 0.05f && std::fabs(b1[i].y - b0[i].y) < 0.05f);
+    }
 }
 
 static void test_matchingFeatures() {                                // vo.h:354-362: the pipeline stereo_callback runs, as a member call
@@ -121,6 +137,7 @@ static void test_matchingFeatures() {                                // vo.h:354
     VisualOdometry vo;
     FeatureSet fs;
     std::vector<Point2f> pl0, pr0, pl1, pr1;
+    vo.stereo_callback(l0.view(), r0.view());                         // primes the cached T0 pyramids, as stereo_callback's frame 0 does (vo.cpp:47-56)
     vo.matchingFeatures(l0.view(), r0.view(), l1.view(), r1.view(), fs, pl0, pr0, pl1, pr1);
     CHECK(fs.points.size() == 121 && pl0.size() == 121 && pl1.size() == 121 && pr0.size() == 121 && pr1.size() == 121);
     for (size_t i = 0; i < pl0.size(); i++) {                        // the scene moves by exactly (+1, 0) in the left view and the
