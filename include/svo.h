@@ -47,7 +47,7 @@ typedef struct {
     double circular_matching_success_threshold; /* vo.h:115 0.15 */
     double max_translation_norm;          /* vo.h:121  0.1 */
     double max_rotation_norm;             /* vo.h:127  0.5 */
-    int win_w, win_h;                     /* vo.h:251  10x10 (square; kernels are instantiated for 7, 10, 15, 21 and 31) */
+    int win_w, win_h;                     /* vo.h:251  10x10 (square, 5 .. 31; 3-channel contexts 5 .. 21) */
     int max_level;                        /* vo.h:252  3 */
     int lk_max_count;                     /* vo.cpp:183 30 */
     double lk_epsilon;                    /* vo.cpp:184 1e-4 */

@@ -96,13 +96,13 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     svo_config cfg;
     if (cfg_in) cfg = *cfg_in; else svo_config_default(&cfg);
     if (n_seq < 1 || width < 16 || height < 16) return fail_arg("n_seq >= 1 and width/height >= 16 required");
-    if (cfg.win_w != cfg.win_h || !lk_window_supported(cfg.win_w)) return fail_arg("unsupported LK window (square 7, 10, 15, 21 or 31)");
+    if (cfg.win_w != cfg.win_h || !lk_window_supported(cfg.win_w)) return fail_arg("unsupported LK window (square, 5 .. 31)");
     if (width <= cfg.win_w || height <= cfg.win_h) return fail_arg("image must be larger than the LK window");
     if (cfg.features_per_bucket != 1) return fail_arg("the frame pipeline supports features_per_bucket == 1 (use svo_bucket_filter for other capacities)");
     if (cfg.buckets_along_height < 1 || cfg.buckets_along_width < 1 || cfg.ransac_iterations < 1) return fail_arg("bad bucket grid / ransac_iterations");
     if (cfg.channels == 0) cfg.channels = 1;
     if (cfg.channels != 1 && cfg.channels != 3) return fail_arg("channels must be 1 or 3");
-    if (!lk_window_supported_cn(cfg.win_w, cfg.channels)) return fail_arg("this LK window is not built for 3-channel input (7, 10, 15, 21 are)");
+    if (!lk_window_supported_cn(cfg.win_w, cfg.channels)) return fail_arg("this LK window is not built for 3-channel input (5 .. 21 are)");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail_arg("no such HIP device");

@@ -751,11 +751,18 @@ static int lk_chunk() { static int v = -1; if (v < 0) { const char* e = getenv("
 static int lk_xcd_mapping() { static int v = -1; if (v < 0) { const char* e = getenv("SVO_LK_XCD"); v = e ? atoi(e) : 0; } return v; }
 // (window, lanes per feature) instantiations; the FIRST entry of a window is its default, the others are selectable with
 // SVO_LK_G=<lanes> for measurement.
-#define LK_FOR_EACH_WINDOW(X) X(7, 16) X(10, 16) X(15, 32) X(15, 64) X(21, 64) X(21, 32) X(31, 64)
+// winSize is a mutable member in the reference (vo.h:251), so every square window from 5 to 31 is built: the tuned entries
+// first (lanes per feature chosen by measurement), then the generic one-wave-per-feature form for all other sizes — the same
+// code (LkLayout derives the segment shape from W), just not tuned.
+#define LK_FOR_EACH_WINDOW_TUNED(X) X(7, 16) X(10, 16) X(15, 32) X(15, 64) X(21, 64) X(21, 32) X(31, 64)
+#define LK_FOR_EACH_WINDOW_GENERIC(X) X(5, 64) X(6, 64) X(8, 64) X(9, 64) X(11, 64) X(12, 64) X(13, 64) X(14, 64) X(16, 64) X(17, 64) X(18, 64) \
+    X(19, 64) X(20, 64) X(22, 64) X(23, 64) X(24, 64) X(25, 64) X(26, 64) X(27, 64) X(28, 64) X(29, 64) X(30, 64)
+#define LK_FOR_EACH_WINDOW(X) LK_FOR_EACH_WINDOW_TUNED(X) LK_FOR_EACH_WINDOW_GENERIC(X)
 
-// 3-channel (BGR) instantiations: one per window, at the window's default lanes-per-feature (w = 31 would need 48 pixels of
-// template and search window per lane, more registers than a wave has)
-#define LK_FOR_EACH_WINDOW_CN3(X) X(7, 16) X(10, 16) X(15, 32) X(21, 64)
+// 3-channel (BGR) instantiations: one per window up to 21, at the window's default lanes-per-feature (beyond that a lane would
+// hold three planes of >= 11 pixels of template and search window: more registers than a wave has)
+#define LK_FOR_EACH_WINDOW_CN3(X) X(7, 16) X(10, 16) X(15, 32) X(21, 64) X(5, 64) X(6, 64) X(8, 64) X(9, 64) X(11, 64) X(12, 64) X(13, 64) \
+    X(14, 64) X(16, 64) X(17, 64) X(18, 64) X(19, 64) X(20, 64)
 
 // Smallest float x with (double)(float)(x / (2 w^2)) >= threshold — found by bisection over the floats in their numeric order
 // (IEEE f32 division on the host, the same operation the kernel would do).  +inf if no finite float qualifies.

@@ -175,6 +175,49 @@ def test_lk_track_bit_exact(api, win, lv, shift):
     assert wst.sum() > 100        # the case is not vacuous
 
 
+@pytest.mark.parametrize("win", [w for w in range(5, 32) if w not in (7, 10, 15, 21, 31)])
+def test_lk_any_square_window_bit_exact(api, win):
+    """winSize is a mutable member of the reference (vo.h:251): every square window 5..31 is built (the generic
+    one-wave-per-feature form for the sizes that are not tuned) and must match the oracle bit for bit — a single LK pass
+    with points on and over the borders, and the fused four-pass circular matching."""
+    a = scenes.random_texture(160, 256, 30 + win, smooth=2)
+    b = scenes.shift_image(a, 3, -2)
+    b = np.clip(b.astype(np.int32) + np.random.default_rng(win).integers(-2, 3, b.shape), 0, 255).astype(np.uint8)
+    pts = lk_points(256, 160, 160, win)
+    got, gst = api.calcOpticalFlowPyrLK(a, b, pts, win, 2)
+    pa, pb = orc.Pyramid(a, (win, win), 2), orc.Pyramid(b, (win, win), 2)
+    want, wst = orc.lk_track(pa, pb, pts, (win, win), 2)
+    assert np.array_equal(gst, wst) and np.array_equal(bits(got), bits(want)) and wst.sum() > 50
+    c, d = scenes.shift_image(a, 0, 1), scenes.shift_image(b, 0, 1)              # "right" views: one row lower
+    cfg = api.default_config(win_w=win, win_h=win, max_level=2)
+    res = api.circularMatching(cfg, a, c, b, d, pts)
+    P = [orc.Pyramid(i, (win, win), 2) for i in (a, c, b, d)]
+    ref = orc.circular_match(P[0], P[1], P[2], P[3], pts, orc.default_config(win_w=win, win_h=win, max_level=2))
+    assert np.array_equal(res[4], ref[4]) and res[4].sum() > 30
+    for g, o in zip(res[:4], ref[:4]):
+        assert np.array_equal(bits(g), bits(o))
+
+
+def test_odd_window_in_the_frame_pipeline(api):
+    """A window that is not one of the tuned sizes through the whole stereo_callback (gray and BGR contexts)."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=320, height=160, cx=160.0, cy=80.0)
+    seq = syn.StereoSequence(cal=cal, n_frames=3, seed=77, step=0.3)
+    Pl, Pr = syn.projection_matrices(cal)
+    for win, cn in ((13, 1), (18, 3), (26, 1)):
+        over = dict(win_w=win, win_h=win, max_level=2, max_translation_norm=2.0, channels=cn)
+        g = api.VisualOdometry(cfg=api.default_config(**over)); g.initalize_projection_matricies(Pl, Pr)
+        o = orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl, Pr)
+        for k in range(3):
+            L, R = seq.left[k], seq.right[k]
+            if cn == 3:
+                L = np.ascontiguousarray(np.stack([L, np.roll(L, 1, 0), 255 - L], -1)); R = np.ascontiguousarray(np.stack([R, np.roll(R, 1, 0), 255 - R], -1))
+            ok_g, T_g = g.stereo_callback(L, R); ok_o, T_o = o.stereo_callback(L, R)
+            assert ok_g == ok_o and g.stats.as_dict() == {f[0]: getattr(o.stats, f[0]) for f in o.stats._fields_}, (win, cn, k)
+            assert np.array_equal(bits(g.features()[0]), bits(o.features()[0])) and np.abs(T_g - T_o).max() < 1e-6
+        assert ok_g, (win, cn)
+
+
 def test_lk_flat_image_fails_min_eig(api):
     a = np.full((100, 120), 77, np.uint8)
     pts = lk_points(120, 100, 40, 3)
