@@ -36,7 +36,7 @@ typedef struct {
     int bucket_start_row;                 /* vo.h:53   4   */
     int buckets_along_height;             /* vo.h:60   92  */
     int buckets_along_width;              /* vo.h:61   160 */
-    int features_per_bucket;              /* vo.h:65   1   (the frame pipeline supports 1 only) */
+    int features_per_bucket;              /* vo.h:65   1   (1 .. 64; 1 takes the fused argmax path, larger capacities the general Bucket::add_feature walk) */
     int features_threshold;               /* vo.h:71   15  */
     int pre_matching_feature_threshold;   /* vo.h:78   100 */
     int age_threshold;                    /* vo.h:84   20  */
@@ -190,7 +190,9 @@ int svo_triangulate(int device, const float Pl[12], const float Pr[12], int n, c
 
 /* replaces: cameraToWorld(K, cameraPoints, worldPoints, rotation, translation) -> pair<inliers, success>
  * (vo.h:452-456, vo.cpp:282-313) = cv::solvePnPRansac(.., useExtrinsicGuess, iterations, reprojErr, confidence, inliers, ITERATIVE).
- * K 3x3 f32; R (3x3 f64) and t (3 f64) in/out; inliers: int32[n]; *success = the pair's .second. */
+ * K 3x3 f32; R (3x3 f64) and t (3 f64) in/out; inliers: int32[n]; *success = the pair's .second.
+ * Small inputs follow cv::solvePnPRansac: n == 5 is one direct EPnP solve and n == 4 one direct P3P solve (every point an
+ * inlier, no RANSAC, no refine); n < 4 is SVO_ERR_ARG (OpenCV asserts npoints >= 4). */
 int svo_camera_to_world(int device, const float K[9], int n, const float* cam_pts, const float* world_pts,
                         double R[9], double t[3], int* inliers, int* n_inliers, int* success,
                         int ransac_iterations, float reproj_error, float confidence, int* iters_run);

@@ -168,6 +168,8 @@ int      orc_rng_uniform(orc_rng* r, int a, int b);
 int      orc_ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
 
 /* EPnP on n>=4 points (object f64, image pixel coords f64). K = fx,fy,cx,cy. Outputs R (row-major), t. Returns mean reproj err. */
+/* cv::solvePnP(SOLVEPNP_P3P) on exactly four points (orc_p3p.c): the branch solvePnPRansac takes for npoints == 4 */
+int orc_p3p(const double obj[12], const double img[8], double fx, double fy, double cx, double cy, double R[9], double t[3]);
 double orc_epnp(int n, const double* obj, const double* img, double fx, double fy, double cx, double cy,
                 double R[9], double t[3]);
 /* Levenberg–Marquardt refine as cvFindExtrinsicCameraParams2(useExtrinsicGuess=1). rvec,tvec in/out. returns iterations used */

@@ -480,16 +480,41 @@ int orc_camera_to_world(const float K[9], int n, const float* cam_pts, const flo
     int i, iter, max_good = 0, iters_run = 0;
     *n_inliers = 0;
     if (dbg) { dbg[0] = 0; dbg[1] = 0; }
-    if (n < model_points) return 0;       /* the P3P (npoints==4) branch is unreachable behind vo.cpp:82 */
+    if (n < 4) return 0;                  /* CV_Assert(npoints >= 4): the reference would throw; the oracle reports failure */
+    if (n <= model_points) {
+        /* solvepnp.cpp: `if (model_points == npoints)` — with 4 points the kernel is P3P (model_points = 4), with 5 it is EPnP:
+         * ONE direct solvePnP on all points, every point an inlier, no RANSAC and no refine.  The pose still makes the
+         * Rodrigues round trip of cameraToWorld (rvec out of solvePnP, vo.cpp:308 back to a matrix). */
+        double rvec[3];
+        int ok;
+        if (n == 4) {
+            double fx = K[0], fy = K[4], cx = K[2], cy = K[5], obj[12], img[8];
+            for (i = 0; i < 4; i++) {
+                obj[3 * i] = world_pts[3 * i]; obj[3 * i + 1] = world_pts[3 * i + 1]; obj[3 * i + 2] = world_pts[3 * i + 2];
+                /* undistortPoints(.., P = cameraMatrix) on CV_32FC2 with zero distortion: normalise and re-project in f64, store f32 */
+                img[2 * i] = (double)(float)((((double)cam_pts[2 * i] - cx) * (1. / fx)) * fx + cx);
+                img[2 * i + 1] = (double)(float)((((double)cam_pts[2 * i + 1] - cy) * (1. / fy)) * fy + cy);
+            }
+            ok = orc_p3p(obj, img, fx, fy, cx, cy, bestR, bestT);
+        } else {
+            int idx[5] = {0, 1, 2, 3, 4};
+            epnp_on_subset(K, world_pts, cam_pts, idx, 5, bestR, bestT);
+            ok = 1;
+        }
+        if (!ok) return 0;
+        orc_rodrigues_to_vector(bestR, rvec);
+        orc_rodrigues_to_matrix(rvec, R, NULL);           /* vo.cpp:308 */
+        memcpy(t, bestT, sizeof(double) * 3);
+        for (i = 0; i < n; i++) inliers[i] = i;
+        *n_inliers = n;
+        if (dbg) { dbg[0] = 0; dbg[1] = n; }
+        return 1;
+    }
     uint8_t* mask = (uint8_t*)malloc((size_t)n);
     uint8_t* best_mask = (uint8_t*)malloc((size_t)n);
     double thr = (double)reproj_error;
     float thr2 = (float)(thr * thr);
-    if (n == model_points) {
-        int idx[5] = {0, 1, 2, 3, 4};
-        epnp_on_subset(K, world_pts, cam_pts, idx, 5, bestR, bestT);
-        memset(best_mask, 1, (size_t)n); max_good = n;
-    } else {
+    {
         orc_rng rng; orc_rng_init(&rng, (uint64_t)-1);
         int niters = ransac_iterations > 1 ? ransac_iterations : 1;
         for (iter = 0; iter < niters; iter++) {

@@ -98,7 +98,7 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     if (n_seq < 1 || width < 16 || height < 16) return fail_arg("n_seq >= 1 and width/height >= 16 required");
     if (cfg.win_w != cfg.win_h || !lk_window_supported(cfg.win_w)) return fail_arg("unsupported LK window (square, 5 .. 31)");
     if (width <= cfg.win_w || height <= cfg.win_h) return fail_arg("image must be larger than the LK window");
-    if (cfg.features_per_bucket != 1) return fail_arg("the frame pipeline supports features_per_bucket == 1 (use svo_bucket_filter for other capacities)");
+    if (cfg.features_per_bucket < 1 || cfg.features_per_bucket > 64) return fail_arg("features_per_bucket must be 1 .. 64");
     if (cfg.buckets_along_height < 1 || cfg.buckets_along_width < 1 || cfg.ransac_iterations < 1) return fail_arg("bad bucket grid / ransac_iterations");
     if (cfg.channels == 0) cfg.channels = 1;
     if (cfg.channels != 1 && cfg.channels != 3) return fail_arg("channels must be 1 or 3");
@@ -117,7 +117,7 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     d.bucket_h = (height + cfg.buckets_along_height - 1) / cfg.buckets_along_height;     // feature_set.cpp:91-93,103-104
     d.bucket_w = (width + cfg.buckets_along_width - 1) / cfg.buckets_along_width;
     int rows = cfg.buckets_along_height - cfg.bucket_start_row; if (rows < 0) rows = 0;
-    d.CAP = rows * cfg.buckets_along_width;
+    d.CAP = rows * cfg.buckets_along_width * cfg.features_per_bucket;
     if (d.CAP < 64) d.CAP = 64;
     if (cap_override > d.CAP) d.CAP = cap_override;
     c->lk_grid = (cfg.max_features > 0 && cfg.max_features < d.CAP) ? cfg.max_features : d.CAP;
@@ -131,6 +131,13 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     if (d.CN == 3) ALLOC(d.fastimg, B * 3 * (size_t)width * (size_t)height + 256);
     for (int k = 0; k < 2; k++) { ALLOC(d.feat_xy[k], B * CAP); ALLOC(d.feat_age[k], B * CAP); ALLOC(d.feat_str[k], B * CAP); }
     ALLOC(d.bucket_keys, B * (size_t)d.NB);
+    if (cfg.features_per_bucket > 1) {
+        d.KPCAP = d.CAP + ((width + 1) / 2) * ((height + 1) / 2);       // strict 3x3 NMS: at most one keypoint per 2x2 block
+        const size_t KC = (size_t)d.KPCAP, SL = (size_t)d.NB * cfg.features_per_bucket;
+        ALLOC(d.score, B * (size_t)width * height); ALLOC(d.kp_rows, B * (size_t)height);
+        ALLOC(d.cand_xy, B * KC); ALLOC(d.cand_age, B * KC); ALLOC(d.cand_str, B * KC); ALLOC(d.n_cand, B);
+        ALLOC(d.slot_xy, B * SL); ALLOC(d.slot_age, B * SL); ALLOC(d.slot_str, B * SL); ALLOC(d.slot_n, B * (size_t)d.NB);
+    }
     ALLOC(d.pl0, B * CAP); ALLOC(d.pl1, B * CAP); ALLOC(d.pr1, B * CAP); ALLOC(d.pr0, B * CAP); ALLOC(d.plc, B * CAP);
     ALLOC(d.okmask, B * CAP);
     ALLOC(d.tl0, B * CAP); ALLOC(d.tr0, B * CAP); ALLOC(d.tl1, B * CAP); ALLOC(d.tr1, B * CAP);
@@ -699,7 +706,7 @@ extern "C" int svo_camera_to_world(int device, const float K[9], int n, const fl
                                    int ransac_iterations, float reproj_error, float confidence, int* iters_run) {
     if (!K || !R || !t || !n_inliers || !success || n < 0 || (n > 0 && (!cam_pts || !world_pts))) return fail_arg("bad arguments");
     *n_inliers = 0; *success = 0; if (iters_run) *iters_run = 0;
-    if (n < 6) return SVO_OK;      // fewer points than the 5-point kernel can sample from: the reference guards with >15 (vo.cpp:82)
+    if (n < 4) return fail_arg("cameraToWorld needs at least 4 points (cv::solvePnPRansac asserts npoints >= 4)");
     svo_config cfg; svo_config_default(&cfg);
     cfg.ransac_iterations = ransac_iterations > 1 ? ransac_iterations : 1;
     cfg.ransac_reprojection_error = reproj_error; cfg.ransac_confidence = confidence;
@@ -713,8 +720,8 @@ extern "C" int svo_camera_to_world(int device, const float K[9], int n, const fl
     HIPCHK(hipMemcpyAsync(c->d.tl1, cam_pts, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d.world, world_pts, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
     if ((rc = set_state(c, hs)) != SVO_OK) return rc;
-    launch_pnp_subsets(c->d, c->stream);
-    launch_pnp(c->d, c->stream);
+    if (n == 4) launch_pnp_p3p(c->d, c->stream);                                 // solvepnp.cpp: npoints == 4 -> one direct P3P
+    else { launch_pnp_subsets(c->d, c->stream); launch_pnp(c->d, c->stream); }   // n == 5: one direct EPnP (handled on the device)
     HIPCHK(hipGetLastError());
     if ((rc = read_state(c, 0, &hs)) != SVO_OK) return rc;
     if (iters_run) *iters_run = hs.pnp_iters;

@@ -56,6 +56,14 @@ struct DevBuffers {
                                                // the single-channel 'image' cv::FAST sees in a BGR Mat
     float2* feat_xy[2]; int* feat_age[2]; int* feat_str[2];   // [B][CAP] each, double-buffered
     unsigned long long* bucket_keys;           // [B][NB]
+    // features_per_bucket > 1 only (the general Bucket::add_feature walk; the default capacity 1 is an argmax and needs none of it):
+    int KPCAP;                                 // candidate capacity per sequence = CAP (existing tracks) + keypoints one FAST pass can return
+    uint8_t* score;                            // [B][W*H] NMS-surviving FAST scores of the pass
+    int* kp_rows;                              // [B][H] keypoints per image row -> exclusive offsets
+    float2* cand_xy; int* cand_age; int* cand_str;   // [B][KPCAP] the pass's input in the reference's order: tracks, then keypoints in raster order
+    int* n_cand;                               // [B]
+    float2* slot_xy; int* slot_age; int* slot_str;   // [B][NB][features_per_bucket]
+    int* slot_n;                               // [B][NB]
     float2 *pl0, *pl1, *pr1, *pr0, *plc;       // [B][CAP] raw LK outputs
     uint8_t* okmask;                           // [B][CAP] bit0 circular ok, bit1 in-bounds
     float2 *tl0, *tr0, *tl1, *tr1;             // [B][CAP] compacted tracks
@@ -88,6 +96,7 @@ void launch_compact(const DevBuffers& d, hipStream_t s);
 void launch_triangulate(const DevBuffers& d, hipStream_t s);
 void launch_pnp(const DevBuffers& d, hipStream_t s);                   // expects the subsets drawn (launch_triangulate does it)
 void launch_pnp_subsets(const DevBuffers& d, hipStream_t s);
+void launch_pnp_p3p(const DevBuffers& d, hipStream_t s);                // exactly four points: one P3P, no RANSAC (stage API only)
 void launch_inverse_transform(const double* R, const double* t, double* T, hipStream_t s);   // device pointers
 void launch_frame_end(const DevBuffers& d, int ring_slot, hipStream_t s);
 

@@ -230,21 +230,25 @@ __device__ __forceinline__ unsigned long long make_bucket_key(int score, unsigne
     return ((unsigned long long)s << 48) | ((unsigned long long)(0xFFFFFFFFu - order) << 16) | (unsigned long long)(strength & 0xFFFF);
 }
 
-template <bool TO_BUCKETS>
+// MODE 0: frame pipeline, survivors go straight to the bucket keys (features_per_bucket == 1).  MODE 1: one image -> score map
+// (stage API).  MODE 2: frame pipeline -> per-sequence score map (features_per_bucket > 1: the general walk needs the keypoint list).
+template <int MODE>
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* img_single, int w_single, int h_single, uint8_t* score_out,
                                               DevBuffers d, int pass, int threshold) {
+    constexpr bool TO_BUCKETS = MODE == 0;
     __shared__ __attribute__((aligned(4))) uint8_t pix[FT_PH][FT_PW + 4];
     __shared__ uint8_t sc[FT_SH][FT_SW + 2];
     __shared__ unsigned short cand[FT_SH * FT_SW];               // screened pixels of the tile (order is irrelevant)
     __shared__ int ncand;
     const int seq = blockIdx.z;
     int W, H; const uint8_t* img;
-    if (TO_BUCKETS) {
+    if (MODE != 1) {
         const SeqState& s = d.st[seq];
         if (pass == 0 ? !s.active : !s.do_second) return;
         W = d.geom.W; H = d.geom.H;
         // FAST runs on the PREVIOUS left image (vo.cpp:325); for a BGR context on the byte image cv::FAST really scans
         img = d.CN == 3 ? d.fastimg + fastimg_index(d, seq, s.slot_img_t0) : d.pyr + pyr_index(d, seq, s.slot_img_t0, 0);
+        if (MODE == 2) score_out = d.score + (size_t)seq * W * H;
     } else { W = w_single; H = h_single; img = img_single; }
     if (threshold < 0) threshold = 0;
     if (threshold > 255) threshold = 255;
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* img_single, int w_s
 void launch_fast_score_map(const uint8_t* img_dev, int w, int h, int threshold, uint8_t* score_dev, hipStream_t st) {
     DevBuffers dummy = {};
     dim3 g((w + FT_W - 1) / FT_W, (h + FT_H - 1) / FT_H, 1);
-    hipLaunchKernelGGL(k_fast<false>, g, dim3(256), 0, st, img_dev, w, h, score_dev, dummy, 0, threshold);
+    hipLaunchKernelGGL(k_fast<1>, g, dim3(256), 0, st, img_dev, w, h, score_dev, dummy, 0, threshold);
 }
 
 // raster-ordered compaction of a score map into keypoints (cv::FAST output order + KeyPoint::convert, feature_set.cpp:62-66)
@@ -449,13 +453,140 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_bucket_emit(DevBuffers d, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// features_per_bucket > 1 inside the frame pipeline: FeatureSet::appendFeaturesFromImage as written (feature_set.cpp:75-89):
+// the pass's input list = existing tracks, then cv::FAST's keypoints in raster order (age 0, strength = response), walked in
+// that order through Bucket::add_feature (fill, then replace the first minimum iff strictly better, :20-53), emitted in
+// bucket-raster order (:132-146).  One thread per bucket walks the whole list: O(N x buckets), the price of a capacity the
+// reference itself only uses in its unit tests (main.cpp:125, 152-157); the default capacity 1 never comes here.
+// ------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ bool pass_runs(const SeqState& s, int pass) { return pass == 0 ? s.active : s.do_second; }
+
+__global__ void k_gen_row_count(DevBuffers d, int pass) {
+    const int seq = blockIdx.y, y = blockIdx.x, W = d.geom.W, H = d.geom.H;
+    if (!pass_runs(d.st[seq], pass)) return;
+    const uint8_t* score = d.score + (size_t)seq * W * H;
+    int cnt = 0;
+    for (int x = threadIdx.x; x < W; x += 64) cnt += score[(size_t)y * W + x] != 0;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (threadIdx.x == 0) d.kp_rows[(size_t)seq * H + y] = cnt;
+}
+__global__ void k_gen_scan_rows(DevBuffers d, int pass) {          // one lane per sequence; H is a few hundred
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= d.B) return;
+    SeqState& s = d.st[seq];
+    if (!pass_runs(s, pass)) return;
+    int* rows = d.kp_rows + (size_t)seq * d.geom.H;
+    int acc = s.n_feat;                                              // keypoints are appended after the existing tracks
+    for (int y = 0; y < d.geom.H; y++) { int c = rows[y]; rows[y] = acc; acc += c; }
+    d.n_cand[seq] = acc < d.KPCAP ? acc : d.KPCAP;
+    s.n_old = s.n_feat;
+}
+__global__ void k_gen_emit_candidates(DevBuffers d, int pass) {
+    const int seq = blockIdx.y, W = d.geom.W, H = d.geom.H;
+    const SeqState& s = d.st[seq];
+    if (!pass_runs(s, pass)) return;
+    const size_t co = (size_t)seq * d.KPCAP, fo = (size_t)seq * d.CAP;
+    if ((int)blockIdx.x == H) {                                      // the extra block copies the existing tracks to the head of the list
+        const int fb = s.feat_buf;
+        for (int i = threadIdx.x; i < s.n_feat; i += 64) {
+            d.cand_xy[co + i] = d.feat_xy[fb][fo + i]; d.cand_age[co + i] = d.feat_age[fb][fo + i]; d.cand_str[co + i] = d.feat_str[fb][fo + i];
+        }
+        return;
+    }
+    const int y = blockIdx.x;
+    const uint8_t* score = d.score + (size_t)seq * W * H;
+    int base = d.kp_rows[(size_t)seq * H + y];
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + threadIdx.x;
+        const int sc = x < W ? score[(size_t)y * W + x] : 0;
+        const unsigned long long m = __ballot(sc != 0);
+        if (sc) {
+            const int idx = base + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+            if (idx < d.KPCAP) { d.cand_xy[co + idx] = make_float2((float)x, (float)y); d.cand_age[co + idx] = 0; d.cand_str[co + idx] = sc; }   // feature_set.cpp:83-87
+        }
+        base += __popcll(m);
+    }
+}
+__global__ void k_gen_bucket_walk(DevBuffers d, int pass) {
+    const int seq = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= d.NB || !pass_runs(d.st[seq], pass)) return;
+    const int baw = d.cfg.buckets_along_width, bah = d.cfg.buckets_along_height, per = d.cfg.features_per_bucket;
+    const int cap = (b / baw) >= d.cfg.bucket_start_row ? per : 0;                     // feature_set.cpp:113-116
+    const size_t co = (size_t)seq * d.KPCAP, so = ((size_t)seq * d.NB + b) * per;
+    float2* sx = d.slot_xy + so; int* sa = d.slot_age + so; int* ss = d.slot_str + so;
+    const int n = d.n_cand[seq], fthr = d.cfg.fast_threshold;
+    int cnt = 0;
+    for (int i = 0; i < n && cap > 0; i++) {
+        const float2 p = d.cand_xy[co + i];
+        const int bh = (int)(p.y / (float)d.bucket_h), bw = (int)(p.x / (float)d.bucket_w);   // :122-123
+        if (bh < 0 || bh >= bah || bw < 0 || bw >= baw || bh * baw + bw != b) continue;
+        const int a = d.cand_age[co + i], st = d.cand_str[co + i];
+        if (a >= d.cfg.age_threshold) continue;                                        // :26
+        if (cnt < cap) { sx[cnt] = p; sa[cnt] = a; ss[cnt] = st; cnt++; }
+        else {
+            const int score = a + (st - fthr) / 20;
+            int smin = sa[0] + (ss[0] - fthr) / 20, imin = 0;
+            for (int k = 1; k < cnt; k++) { const int c = sa[k] + (ss[k] - fthr) / 20; if (c < smin) { smin = c; imin = k; } }
+            if (score > smin) { sx[imin] = p; sa[imin] = a; ss[imin] = st; }
+        }
+    }
+    d.slot_n[(size_t)seq * d.NB + b] = cnt;
+}
+__global__ __launch_bounds__(EMIT_THREADS) void k_gen_bucket_emit(DevBuffers d, int pass) {
+    const int seq = blockIdx.x;
+    SeqState& s = d.st[seq];
+    if (!pass_runs(s, pass)) return;
+    __shared__ int wave_tot[EMIT_WAVES];
+    __shared__ int s_total;
+    const int fb = s.feat_buf, nb = d.NB, per = d.cfg.features_per_bucket;
+    const int* sn = d.slot_n + (size_t)seq * nb;
+    float2* nxy = d.feat_xy[fb ^ 1] + (size_t)seq * d.CAP; int* nage = d.feat_age[fb ^ 1] + (size_t)seq * d.CAP; int* nstr = d.feat_str[fb ^ 1] + (size_t)seq * d.CAP;
+    const int chunk = (nb + EMIT_THREADS - 1) / EMIT_THREADS;
+    const int b0 = threadIdx.x * chunk < nb ? threadIdx.x * chunk : nb, b1 = (b0 + chunk < nb) ? b0 + chunk : nb;
+    int cnt = 0;
+    for (int b = b0; b < b1; b++) cnt += sn[b];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < EMIT_WAVES; i++) { int t = wave_tot[i]; wave_tot[i] = acc; acc += t; } s_total = acc; }
+    __syncthreads();
+    int pos = wave_tot[wv] + incl - cnt;
+    for (int b = b0; b < b1; b++) {
+        const size_t so = ((size_t)seq * nb + b) * per;
+        for (int k = 0; k < sn[b]; k++, pos++)
+            if (pos < d.CAP) { nxy[pos] = d.slot_xy[so + k]; nage[pos] = d.slot_age[so + k]; nstr[pos] = d.slot_str[so + k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = s_total < d.CAP ? s_total : d.CAP;
+        s.n_feat = total; s.feat_buf = fb ^ 1;
+        s.stats.n_after_detect = total;
+        if (pass == 0) s.do_second = total < d.cfg.pre_matching_feature_threshold;   // vo.cpp:327
+        else s.stats.second_pass = 1;
+    }
+}
+static void launch_detect_general(const DevBuffers& d, int pass, int th, hipStream_t st) {
+    const int W = d.geom.W, H = d.geom.H;
+    dim3 g((W + FT_W - 1) / FT_W, (H + FT_H - 1) / FT_H, d.B);
+    hipLaunchKernelGGL(k_fast<2>, g, dim3(256), 0, st, (const uint8_t*)nullptr, 0, 0, (uint8_t*)nullptr, d, pass, th);
+    hipLaunchKernelGGL(k_gen_row_count, dim3(H, d.B), dim3(64), 0, st, d, pass);
+    hipLaunchKernelGGL(k_gen_scan_rows, dim3((d.B + 63) / 64), dim3(64), 0, st, d, pass);
+    hipLaunchKernelGGL(k_gen_emit_candidates, dim3(H + 1, d.B), dim3(64), 0, st, d, pass);
+    hipLaunchKernelGGL(k_gen_bucket_walk, dim3((d.NB + 255) / 256, d.B), dim3(256), 0, st, d, pass);
+    hipLaunchKernelGGL(k_gen_bucket_emit, dim3(d.B), dim3(EMIT_THREADS), 0, st, d, pass);
+}
+
 void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t st) {
     int th = pass == 0 ? d.cfg.fast_threshold : d.cfg.fast_threshold / 4;            // vo.cpp:325 / :329-330
     if (th_override >= 0) th = th_override;
+    if (d.cfg.features_per_bucket > 1) { launch_detect_general(d, pass, th, st); return; }
     hipLaunchKernelGGL(k_bucket_clear, dim3((d.NB + 255) / 256, d.B), dim3(256), 0, st, d, pass);
     hipLaunchKernelGGL(k_bucket_offer_old, dim3((d.CAP + 255) / 256, d.B), dim3(256), 0, st, d, pass);
     dim3 g((d.geom.W + FT_W - 1) / FT_W, (d.geom.H + FT_H - 1) / FT_H, d.B);
-    hipLaunchKernelGGL(k_fast<true>, g, dim3(256), 0, st, (const uint8_t*)nullptr, 0, 0, (uint8_t*)nullptr, d, pass, th);
+    hipLaunchKernelGGL(k_fast<0>, g, dim3(256), 0, st, (const uint8_t*)nullptr, 0, 0, (uint8_t*)nullptr, d, pass, th);
     hipLaunchKernelGGL(k_bucket_emit, dim3(d.B), dim3(EMIT_THREADS), 0, st, d, pass);
 }
 

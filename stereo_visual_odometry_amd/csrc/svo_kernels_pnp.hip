@@ -59,6 +59,11 @@ void launch_triangulate(const DevBuffers& d, hipStream_t st) {
 // of the 32-bit division sequence.
 static __device__ void pnp_draw_subsets(const DevBuffers& d, int seq, unsigned n) {
     if (n < 2) return;
+    if (n == 5) {                                                    // model_points == npoints: one direct solve on all five (solvepnp.cpp)
+        int* o5 = d.subsets + (size_t)seq * d.K * 5;
+        for (int i = 0; i < 5; i++) o5[i] = i;
+        return;
+    }
     unsigned long long state = 0xFFFFFFFFFFFFFFFFull;                // RNG rng((uint64)-1)
     const unsigned long long recip = 0xFFFFFFFFFFFFFFFFull / n + 1ull;
     int* out = d.subsets + (size_t)seq * d.K * 5;
@@ -434,7 +439,8 @@ __global__ __launch_bounds__(EP_G * EP_HPB) void k_pnp_epnp(DevBuffers d, int h0
     const int seq = blockIdx.y;
     const SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
-    const int hend = h0 > 0 ? (s.pnp_need < h1 ? s.pnp_need : h1) : h1;
+    int hend = h0 > 0 ? (s.pnp_need < h1 ? s.pnp_need : h1) : h1;
+    if (s.n_tracks == 5 && hend > 1) hend = 1;                          // five points: a single direct EPnP, no RANSAC
     if (h0 + (int)blockIdx.x * EP_HPB >= hend) return;                  // block-uniform
     const int g = threadIdx.x / EP_G, q = threadIdx.x % EP_G;
     const int h = h0 + blockIdx.x * EP_HPB + g;
@@ -509,6 +515,7 @@ __global__ __launch_bounds__(256) void k_pnp_score(DevBuffers d, int h0, int h1)
     const SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
     if (h >= (h0 > 0 ? (s.pnp_need < h1 ? s.pnp_need : h1) : h1)) return;
+    if (s.n_tracks == 5) return;                                        // direct solve: nothing is scored
     __shared__ int total;
     __shared__ double Rt[12];
     if (threadIdx.x == 0) total = 0;
@@ -565,6 +572,7 @@ __global__ void k_pnp_decide(DevBuffers d, int c0) {
     SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
     const int K = d.K, n = s.n_tracks;
+    if (n == 5) { s.pnp_need = 1; return; }
     const int* good = d.hyp_good + (size_t)seq * K;
     int niters = K > 1 ? K : 1, max_good = 0;
     for (int it = 0; it < niters && it < c0 && it < K; it++) {
@@ -683,8 +691,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
     __shared__ double bestRt[12];
     const int n = s.n_tracks, K = d.K;
     const size_t o = (size_t)seq * d.CAP;
+    const bool direct = n == 5;      // model_points == npoints (solvepnp.cpp): one EPnP on all points, all inliers, no refine
     // ---- replay of RANSACPointSetRegistrator::run's accept / shrink rule over the K precomputed inlier counts
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && direct) { s.pnp_best = 0; s.pnp_iters = 0; s.pnp_good = n; sh.total = 0; }
+    if (threadIdx.x == 0 && !direct) {
         const int* good = d.hyp_good + (size_t)seq * K;
         int niters = K > 1 ? K : 1, max_good = 0, best = -1, iters_run = 0;
         for (int it = 0; it < niters && it < K; it++) {
@@ -709,7 +719,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
         const double thr = (double)d.cfg.ransac_reprojection_error;
         const float thr2 = (float)(thr * thr);
         for (int i = threadIdx.x; i < n; i += PF_THREADS)
-            d.inlier[o + i] = (uint8_t)point_is_inlier(bestRt, fx, fy, cx, cy, d.world + 3 * (o + i), d.tl1[o + i], thr2);
+            d.inlier[o + i] = direct ? (uint8_t)1 : (uint8_t)point_is_inlier(bestRt, fx, fy, cx, cy, d.world + 3 * (o + i), d.tl1[o + i], thr2);
     }
     __syncthreads();
     // ---- Levenberg–Marquardt refine on the inliers (solvePnP ITERATIVE, useExtrinsicGuess; CvLevMarq state machine)
@@ -718,7 +728,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
         rodrigues_to_vector(bestRt, rv);
         sh.param[0] = rv[0]; sh.param[1] = rv[1]; sh.param[2] = rv[2];
         sh.param[3] = bestRt[9]; sh.param[4] = bestRt[10]; sh.param[5] = bestRt[11];
-        sh.lambdaLg10 = -3; sh.iters = 0; sh.state = 0; sh.mode = 1; sh.prevErrNorm = 0; sh.lambda_tab = d.lm_lambda;
+        sh.lambdaLg10 = -3; sh.iters = 0; sh.state = 0; sh.mode = direct ? 2 : 1; sh.prevErrNorm = 0; sh.lambda_tab = d.lm_lambda;
     }
     __syncthreads();
     for (int guard = 0; guard < 1000; guard++) {
@@ -792,6 +802,235 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
         inverse_transform(s.R, s.t, s.last_T);                                                  // vo.cpp:133
         s.ok = 1;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ four points: P3P
+// cv::solvePnPRansac with exactly four points solves ONE P3P (Gao, Hou, Tang, Chang, PAMI 2003, as OpenCV's p3p.cpp does it:
+// quartic in |PA| / |PC|, closed-form |PB| / |PC|, Horn's quaternion alignment, the fourth point picks the branch), every
+// point an inlier, no RANSAC and no refine (solvepnp.cpp: npoints == 4 -> model_points = 4, SOLVEPNP_P3P, model_points ==
+// npoints).  Only the public cameraToWorld reaches it (vo.h:452-456); stereo_callback wants > 15 tracks (vo.cpp:82).
+// One thread: the work is a few hundred flops.  pow / acos / cos make this tolerance-parity, like the LM refine.
+static __device__ int p3p_solve_deg2(double a, double b, double c, double& x1, double& x2) {
+    double delta = b * b - 4 * a * c;
+    if (delta < 0) return 0;
+    double inv_2a = 0.5 / a;
+    if (delta == 0) { x1 = -b * inv_2a; x2 = x1; return 1; }
+    double sd = sqrt(delta);
+    x1 = (-b + sd) * inv_2a; x2 = (-b - sd) * inv_2a;
+    return 2;
+}
+static __device__ int p3p_solve_deg3(double a, double b, double c, double d, double& x0, double& x1, double& x2) {
+    if (a == 0) {
+        if (b == 0) { if (c == 0) return 0; x0 = -d / c; return 1; }
+        x2 = 0;
+        return p3p_solve_deg2(b, c, d, x0, x1);
+    }
+    double inv_a = 1. / a, b_a = inv_a * b, b_a2 = b_a * b_a, c_a = inv_a * c, d_a = inv_a * d;
+    double Q = (3 * c_a - b_a2) / 9, R = (9 * b_a * c_a - 27 * d_a - 2 * b_a * b_a2) / 54;
+    double Q3 = Q * Q * Q, D = Q3 + R * R, b_a_3 = (1. / 3.) * b_a;
+    if (Q == 0) {
+        if (R == 0) { x0 = x1 = x2 = -b_a_3; return 3; }
+        x0 = pow(2 * R, 1 / 3.0) - b_a_3;
+        return 1;
+    }
+    if (D <= 0) {
+        double theta = acos(R / sqrt(-Q3)), sq = sqrt(-Q);
+        x0 = 2 * sq * cos(theta / 3.0) - b_a_3;
+        x1 = 2 * sq * cos((theta + 2 * 3.14159265358979323846) / 3.0) - b_a_3;
+        x2 = 2 * sq * cos((theta + 4 * 3.14159265358979323846) / 3.0) - b_a_3;
+        return 3;
+    }
+    double AD = pow(fabs(R) + sqrt(D), 1.0 / 3.0) * (R > 0 ? 1 : (R < 0 ? -1 : 0));
+    double BD = (AD == 0) ? 0 : -Q / AD;
+    x0 = AD + BD - b_a_3;
+    return 1;
+}
+static __device__ int p3p_solve_deg4(double a, double b, double c, double d, double e, double* x) {
+    if (a == 0) { x[3] = 0; return p3p_solve_deg3(b, c, d, e, x[0], x[1], x[2]); }
+    double inv_a = 1. / a;
+    b *= inv_a; c *= inv_a; d *= inv_a; e *= inv_a;
+    double b2 = b * b, bc = b * c, b3 = b2 * b, r0, r1, r2;
+    int n = p3p_solve_deg3(1, -c, d * b - 4 * e, 4 * c * e - d * d - b2 * e, r0, r1, r2);
+    if (n == 0) return 0;
+    double R2 = 0.25 * b2 - c + r0;
+    if (R2 < 0) return 0;
+    double R = sqrt(R2), inv_R = 1. / R, D2, E2;
+    int nb = 0;
+    if (R < 10E-12) {
+        double temp = r0 * r0 - 4 * e;
+        if (temp < 0) D2 = E2 = -1;
+        else { double st = sqrt(temp); D2 = 0.75 * b2 - 2 * c + 2 * st; E2 = D2 - 4 * st; }
+    } else {
+        double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * inv_R * (4 * bc - 8 * d - b3);
+        D2 = u + v; E2 = u - v;
+    }
+    double b_4 = 0.25 * b, R_2 = 0.5 * R;
+    if (D2 >= 0) { double D = sqrt(D2); nb = 2; x[0] = R_2 + 0.5 * D - b_4; x[1] = x[0] - D; }
+    if (E2 >= 0) {
+        double E = sqrt(E2);
+        if (nb == 0) { x[0] = -R_2 + 0.5 * E - b_4; x[1] = x[0] - E; nb = 2; }
+        else { x[2] = -R_2 + 0.5 * E - b_4; x[3] = x[2] - E; nb = 4; }
+    }
+    return nb;
+}
+static __device__ int p3p_lengths(double (*lengths)[3], const double* distances, const double* cosines) {
+    double p = cosines[0] * 2, q = cosines[1] * 2, r = cosines[2] * 2;
+    double inv_d22 = 1. / (distances[2] * distances[2]);
+    double a = inv_d22 * (distances[0] * distances[0]), b = inv_d22 * (distances[1] * distances[1]);
+    double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r, pr = p * r, pqr = q * pr;
+    if (p2 + q2 + r2 - pqr - 1 == 0) return 0;
+    double ab = a * b, a_2 = 2 * a;
+    double A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
+    if (A == 0) return 0;
+    double a_4 = 4 * a;
+    double B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
+    double C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
+    double D = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
+    double E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
+    double temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr), b0 = b * temp * temp;
+    if (b0 == 0) return 0;
+    double roots[4];
+    int n = p3p_solve_deg4(A, B, C, D, E, roots), nb = 0;
+    if (n == 0) return 0;
+    double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q, inv_b0 = 1. / b0;
+    for (int i = 0; i < n; i++) {
+        double x = roots[i];
+        if (x <= 0) continue;
+        double x2 = x * x;
+        double b1 =
+            ((1 - a - b) * x2 + (q * a - q) * x + 1 - a + b) *
+            (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+              (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * x2 +
+             (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+              pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+             2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+             p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+        if (b1 <= 0) continue;
+        double y = inv_b0 * b1, v = x2 + y * y - x * y * r;
+        if (v <= 0) continue;
+        double Z = distances[2] / sqrt(v);
+        lengths[nb][0] = x * Z; lengths[nb][1] = y * Z; lengths[nb][2] = Z;
+        nb++;
+    }
+    return nb;
+}
+static __device__ void p3p_jacobi4(double* A, double* D, double* U) {      // symmetric 4 x 4 eigen decomposition, cyclic Jacobi
+    double B[4], Z[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0);
+    B[0] = A[0]; B[1] = A[5]; B[2] = A[10]; B[3] = A[15];
+    for (int i = 0; i < 4; i++) D[i] = B[i];
+    for (int iter = 0; iter < 50; iter++) {
+        double sum = fabs(A[1]) + fabs(A[2]) + fabs(A[3]) + fabs(A[6]) + fabs(A[7]) + fabs(A[11]);
+        if (sum == 0.0) return;
+        double tresh = (iter < 3) ? 0.2 * sum / 16. : 0.0;
+        for (int i = 0; i < 3; i++) {
+            for (int j = i + 1; j < 4; j++) {
+                double& aij = A[4 * i + j];
+                double Aij = aij, eps_machine = 100.0 * fabs(Aij);
+                if (iter > 3 && fabs(D[i]) + eps_machine == fabs(D[i]) && fabs(D[j]) + eps_machine == fabs(D[j])) aij = 0.0;
+                else if (fabs(Aij) > tresh) {
+                    double hh = D[j] - D[i], t;
+                    if (fabs(hh) + eps_machine == fabs(hh)) t = Aij / hh;
+                    else {
+                        double theta = 0.5 * hh / Aij;
+                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        if (theta < 0.0) t = -t;
+                    }
+                    hh = t * Aij;
+                    Z[i] -= hh; Z[j] += hh; D[i] -= hh; D[j] += hh;
+                    aij = 0.0;
+                    double c = 1.0 / sqrt(1 + t * t), s = t * c, tau = s / (1.0 + c);
+                    for (int k = 0; k <= i - 1; k++) { double g = A[k * 4 + i], h = A[k * 4 + j]; A[k * 4 + i] = g - s * (h + g * tau); A[k * 4 + j] = h + s * (g - h * tau); }
+                    for (int k = i + 1; k <= j - 1; k++) { double g = A[i * 4 + k], h = A[k * 4 + j]; A[i * 4 + k] = g - s * (h + g * tau); A[k * 4 + j] = h + s * (g - h * tau); }
+                    for (int k = j + 1; k < 4; k++) { double g = A[i * 4 + k], h = A[j * 4 + k]; A[i * 4 + k] = g - s * (h + g * tau); A[j * 4 + k] = h + s * (g - h * tau); }
+                    for (int k = 0; k < 4; k++) { double g = U[k * 4 + i], h = U[k * 4 + j]; U[k * 4 + i] = g - s * (h + g * tau); U[k * 4 + j] = h + s * (g - h * tau); }
+                }
+            }
+        }
+        for (int i = 0; i < 4; i++) { B[i] += Z[i]; D[i] = B[i]; Z[i] = 0; }
+    }
+}
+static __device__ void p3p_align(const double (*M_end)[3], const double (*Xw)[3], double (*R)[3], double* T) {
+    double C_start[3], C_end[3], s[9], Qs[16], evs[4], U[16], q[4];
+    for (int i = 0; i < 3; i++) {
+        C_end[i] = (M_end[0][i] + M_end[1][i] + M_end[2][i]) / 3;
+        C_start[i] = (Xw[0][i] + Xw[1][i] + Xw[2][i]) / 3;
+    }
+    for (int j = 0; j < 3; j++)
+        for (int i = 0; i < 3; i++)
+            s[i * 3 + j] = (Xw[0][i] * M_end[0][j] + Xw[1][i] * M_end[1][j] + Xw[2][i] * M_end[2][j]) / 3 - C_end[j] * C_start[i];
+    for (int i = 0; i < 16; i++) Qs[i] = 0;
+    Qs[0] = s[0] + s[4] + s[8]; Qs[5] = s[0] - s[4] - s[8]; Qs[10] = s[4] - s[8] - s[0]; Qs[15] = s[8] - s[0] - s[4];
+    Qs[4] = Qs[1] = s[5] - s[7]; Qs[8] = Qs[2] = s[6] - s[2]; Qs[12] = Qs[3] = s[1] - s[3];
+    Qs[9] = Qs[6] = s[3] + s[1]; Qs[13] = Qs[7] = s[6] + s[2]; Qs[14] = Qs[11] = s[7] + s[5];
+    p3p_jacobi4(Qs, evs, U);
+    int i_ev = 0;
+    double ev_max = evs[0];
+    for (int i = 1; i < 4; i++) if (evs[i] > ev_max) { ev_max = evs[i]; i_ev = i; }
+    for (int i = 0; i < 4; i++) q[i] = U[i * 4 + i_ev];
+    double q02 = q[0] * q[0], q12 = q[1] * q[1], q22 = q[2] * q[2], q32 = q[3] * q[3];
+    double q0_1 = q[0] * q[1], q0_2 = q[0] * q[2], q0_3 = q[0] * q[3], q1_2 = q[1] * q[2], q1_3 = q[1] * q[3], q2_3 = q[2] * q[3];
+    R[0][0] = q02 + q12 - q22 - q32; R[0][1] = 2. * (q1_2 - q0_3); R[0][2] = 2. * (q1_3 + q0_2);
+    R[1][0] = 2. * (q1_2 + q0_3); R[1][1] = q02 + q22 - q12 - q32; R[1][2] = 2. * (q2_3 - q0_1);
+    R[2][0] = 2. * (q1_3 - q0_2); R[2][1] = 2. * (q2_3 + q0_1); R[2][2] = q02 + q32 - q12 - q22;
+    for (int i = 0; i < 3; i++) T[i] = C_end[i] - (R[i][0] * C_start[0] + R[i][1] * C_start[1] + R[i][2] * C_start[2]);
+}
+
+// one thread per sequence; expects s.n_tracks == 4
+__global__ void k_pnp_p3p(DevBuffers d) {
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= d.B) return;
+    SeqState& s = d.st[seq];
+    if (!seq_live(s) || s.n_tracks != 4) return;
+    const size_t o = (size_t)seq * d.CAP;
+    const double fx = s.K[0], fy = s.K[4], cx = s.K[2], cy = s.K[5];
+    const double inv_fx = 1. / fx, inv_fy = 1. / fy, cx_fx = cx / fx, cy_fy = cy / fy;
+    double obj[12], mu[4], mv[4], mk[3], Xw[3][3], distances[3], cosines[3], lengths[4][3];
+    for (int i = 0; i < 4; i++) {
+        for (int k = 0; k < 3; k++) obj[3 * i + k] = d.world[3 * (o + i) + k];
+        const float2 c = d.tl1[o + i];
+        // undistortPoints(.., P = cameraMatrix) on CV_32FC2 with zero distortion: normalise and re-project in f64, store f32
+        const double u = (double)(float)((((double)c.x - cx) * inv_fx) * fx + cx), v = (double)(float)((((double)c.y - cy) * inv_fy) * fy + cy);
+        mu[i] = inv_fx * u - cx_fx; mv[i] = inv_fy * v - cy_fy;
+    }
+    for (int i = 0; i < 3; i++) {
+        double norm = sqrt(mu[i] * mu[i] + mv[i] * mv[i] + 1);
+        mk[i] = 1. / norm; mu[i] *= mk[i]; mv[i] *= mk[i];
+        for (int k = 0; k < 3; k++) Xw[i][k] = obj[3 * i + k];
+    }
+    distances[0] = sqrt(dist2(obj + 3, obj + 6)); distances[1] = sqrt(dist2(obj, obj + 6)); distances[2] = sqrt(dist2(obj, obj + 3));
+    cosines[0] = mu[1] * mu[2] + mv[1] * mv[2] + mk[1] * mk[2];
+    cosines[1] = mu[0] * mu[2] + mv[0] * mv[2] + mk[0] * mk[2];
+    cosines[2] = mu[0] * mu[1] + mv[0] * mv[1] + mk[0] * mk[1];
+    const int n = p3p_lengths(lengths, distances, cosines);
+    int nb = 0;
+    double best_err = 0, bestR[9], bestT[3];
+    for (int i = 0; i < n; i++) {
+        double M_orig[3][3], Rs[3][3], ts[3];
+        for (int k = 0; k < 3; k++) { M_orig[k][0] = lengths[i][k] * mu[k]; M_orig[k][1] = lengths[i][k] * mv[k]; M_orig[k][2] = lengths[i][k] * mk[k]; }
+        p3p_align(M_orig, Xw, Rs, ts);
+        double X3p = Rs[0][0] * obj[9] + Rs[0][1] * obj[10] + Rs[0][2] * obj[11] + ts[0];
+        double Y3p = Rs[1][0] * obj[9] + Rs[1][1] * obj[10] + Rs[1][2] * obj[11] + ts[1];
+        double Z3p = Rs[2][0] * obj[9] + Rs[2][1] * obj[10] + Rs[2][2] * obj[11] + ts[2];
+        double mu3p = X3p / Z3p, mv3p = Y3p / Z3p;
+        double err = (mu3p - mu[3]) * (mu3p - mu[3]) + (mv3p - mv[3]) * (mv3p - mv[3]);
+        if (nb == 0 || err < best_err) {
+            best_err = err;
+            for (int k = 0; k < 3; k++) { bestR[3 * k] = Rs[k][0]; bestR[3 * k + 1] = Rs[k][1]; bestR[3 * k + 2] = Rs[k][2]; bestT[k] = ts[k]; }
+        }
+        nb++;
+    }
+    s.pnp_iters = 0;
+    if (nb == 0) { s.pnp_best = -1; s.fail_reason = 3; return; }           // solvePnP returned false
+    double rv[3];
+    rodrigues_to_vector(bestR, rv);                                         // rvec out of solvePnP ...
+    rodrigues_to_matrix(rv, s.R, nullptr);                                  // ... and back to a matrix (vo.cpp:308)
+    s.t[0] = bestT[0]; s.t[1] = bestT[1]; s.t[2] = bestT[2];
+    s.pnp_best = 0; s.pnp_good = 4; s.n_inliers = 4;
+    for (int i = 0; i < 4; i++) { d.inlier[o + i] = 1; d.inl_idx[o + i] = i; }
+}
+void launch_pnp_p3p(const DevBuffers& d, hipStream_t st) {
+    hipLaunchKernelGGL(k_pnp_p3p, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
 }
 
 // ---- getInverseTransform (vo.cpp:246-258) as its own one-thread launch, for the stage API ----

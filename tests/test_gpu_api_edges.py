@@ -50,11 +50,12 @@ def test_argument_errors_are_reported_not_crashes(api):
     ctx = C.c_void_p()
     assert api.lib.svo_create(C.byref(cfg), 0, 0, 320, 160, C.byref(ctx)) == api._lib.SVO_ERR_ARG          # n_seq < 1
     assert api.lib.svo_create(C.byref(cfg), 99, 1, 320, 160, C.byref(ctx)) == api._lib.SVO_ERR_ARG         # no such device
-    bad = api.default_config(win_w=12, win_h=12)
-    assert api.lib.svo_create(C.byref(bad), 0, 1, 320, 160, C.byref(ctx)) == api._lib.SVO_ERR_ARG          # unsupported window
-    assert b"window" in api.lib.svo_last_error()
-    bad = api.default_config(features_per_bucket=3)
-    assert api.lib.svo_create(C.byref(bad), 0, 1, 320, 160, C.byref(ctx)) == api._lib.SVO_ERR_ARG
+    for bad in (api.default_config(win_w=33, win_h=33), api.default_config(win_w=4, win_h=4), api.default_config(win_w=12, win_h=10),
+                api.default_config(win_w=25, win_h=25, channels=3)):
+        assert api.lib.svo_create(C.byref(bad), 0, 1, 320, 160, C.byref(ctx)) == api._lib.SVO_ERR_ARG      # unsupported window
+        assert b"window" in api.lib.svo_last_error()
+    for bad in (api.default_config(features_per_bucket=0), api.default_config(features_per_bucket=65)):
+        assert api.lib.svo_create(C.byref(bad), 0, 1, 320, 160, C.byref(ctx)) == api._lib.SVO_ERR_ARG
     api.check(api.lib.svo_create(C.byref(cfg), 0, 1, 320, 160, C.byref(ctx)))
     img = np.zeros((160, 320), np.uint8); T = np.zeros(16)
     assert api.lib.svo_process(ctx, api.ptr(img), api.ptr(img), 320, api.ptr(T), None) == api._lib.SVO_ERR_STATE   # projection not set

@@ -326,6 +326,91 @@ def test_circular_match_parity_stereo_scene(api, win):
 
 
 # ---------------------------------------------------------------- triangulation / PnP
+def _small_pnp_scene(n, seed):
+    rng = np.random.default_rng(seed)
+    K = np.array([[718.856, 0, 607.1928], [0, 718.856, 185.2157], [0, 0, 1]], np.float32)
+    r = rng.normal(0, 0.2, 3); th = np.linalg.norm(r); k = r / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    t = rng.normal(0, 0.3, 3) + [0, 0, 1.0]
+    X = np.concatenate([rng.uniform(-2, 2, (n, 2)), rng.uniform(4, 9, (n, 1))], 1).astype(np.float32)
+    Xc = X.astype(np.float64) @ R.T + t
+    uv = ((Xc[:, :2] / Xc[:, 2:]) * [K[0, 0], K[1, 1]] + [K[0, 2], K[1, 2]]).astype(np.float32)
+    return K, R, t, X, uv
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_camera_to_world_four_points_is_one_p3p(api, seed):
+    """cv::solvePnPRansac with npoints == 4: one direct P3P, all four inliers, no RANSAC, no refine (SURVEY.md A.5) — against the
+    oracle's restatement (pow / acos / cos in the cubic: tolerance, not bits) and against the known pose."""
+    K, R, t, X, uv = _small_pnp_scene(4, seed)
+    (inl, ok), R_g, t_g, iters = api.cameraToWorld(K, uv, X, np.eye(3), np.zeros(3))
+    ok_o, R_o, t_o, inl_o, _ = orc.camera_to_world(K, uv, X, np.eye(3), np.zeros(3))
+    assert ok and ok_o and inl.tolist() == [0, 1, 2, 3] == inl_o.tolist() and iters == 0
+    assert np.abs(R_g - R_o).max() < 1e-9 and np.abs(t_g.reshape(3) - t_o).max() < 1e-8
+    assert np.abs(R_g - R).max() < 2e-4 and np.abs(t_g.reshape(3) - t).max() < 2e-3
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_camera_to_world_five_points_is_one_epnp(api, seed):
+    """npoints == 5 == model_points: one direct EPnP on all points, all inliers, no LM refine."""
+    K, R, t, X, uv = _small_pnp_scene(5, 50 + seed)
+    (inl, ok), R_g, t_g, iters = api.cameraToWorld(K, uv, X, np.eye(3), np.zeros(3))
+    ok_o, R_o, t_o, inl_o, _ = orc.camera_to_world(K, uv, X, np.eye(3), np.zeros(3))
+    assert ok and ok_o and inl.tolist() == [0, 1, 2, 3, 4] == inl_o.tolist() and iters == 0
+    assert np.abs(R_g - R_o).max() < 1e-9 and np.abs(t_g.reshape(3) - t_o).max() < 1e-9
+
+
+def test_camera_to_world_fewer_than_four_points_is_an_error(api):
+    K, R, t, X, uv = _small_pnp_scene(3, 1)
+    with pytest.raises(api._lib.SvoError):
+        api.cameraToWorld(K, uv, X, np.eye(3), np.zeros(3))
+
+
+@pytest.mark.parametrize("per_bucket,grid", [(3, (92, 160)), (2, (20, 30)), (7, (6, 8))])
+def test_features_per_bucket_above_one_in_the_frame_pipeline(api, per_bucket, grid):
+    """FEATURES_PER_BUCKET is a constant of the reference (vo.h:65) that its own tests vary (main.cpp:125, 152-157): capacities
+    above 1 take the general Bucket::add_feature walk inside stereo_callback — feature sets (order included), tracks, masks and
+    counters identical to the oracle on every frame, with ages building up so that the replace-the-minimum rule really fires."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=480, height=200, cx=240.0, cy=100.0)
+    seq = syn.StereoSequence(cal=cal, n_frames=5, seed=31, step=0.3)
+    Pl, Pr = syn.projection_matrices(cal)
+    over = dict(win_w=10, win_h=10, max_translation_norm=2.0, features_per_bucket=per_bucket, buckets_along_height=grid[0], buckets_along_width=grid[1],
+                bucket_start_row=1)
+    g = api.VisualOdometry(cfg=api.default_config(**over)); g.initalize_projection_matricies(Pl, Pr)
+    o = orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl, Pr)
+    full = 0
+    for k in range(5):
+        ok_g, T_g = g.stereo_callback(seq.left[k], seq.right[k]); ok_o, T_o = o.stereo_callback(seq.left[k], seq.right[k])
+        sg = g.stats.as_dict(); so = {f[0]: getattr(o.stats, f[0]) for f in o.stats._fields_}
+        assert ok_g == ok_o and sg == so, (k, sg, so)
+        fg, fo = g.features(), o.features()
+        assert np.array_equal(bits(fg[0]), bits(fo[0])) and np.array_equal(fg[1], fo[1]) and np.array_equal(fg[2], fo[2]), k
+        assert np.abs(T_g - T_o).max() < 1e-6
+        full += so["n_after_detect"]
+    assert ok_g and full > 5 * 100
+
+
+def test_five_tracks_through_the_frame_pipeline(api):
+    """features_threshold below 5 lets a frame reach PnP with exactly five tracks (vo.cpp:82 is max(4, FEATURES_THRESHOLD)):
+    the direct 5-point branch then runs inside stereo_callback, identically to the oracle."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=320, height=160, cx=160.0, cy=80.0)
+    seq = syn.StereoSequence(cal=cal, n_frames=3, seed=11, step=0.3)
+    Pl, Pr = syn.projection_matrices(cal)
+    over = dict(win_w=21, win_h=21, max_translation_norm=5.0, max_rotation_norm=3.0, features_threshold=0, max_features=5)
+    g = api.VisualOdometry(cfg=api.default_config(**over)); g.initalize_projection_matricies(Pl, Pr)
+    o = orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl, Pr)
+    seen5 = False
+    for k in range(3):
+        ok_g, T_g = g.stereo_callback(seq.left[k], seq.right[k]); ok_o, T_o = o.stereo_callback(seq.left[k], seq.right[k])
+        sg = g.stats.as_dict(); so = {f[0]: getattr(o.stats, f[0]) for f in o.stats._fields_}
+        assert ok_g == ok_o and sg == so, (k, sg, so)
+        assert np.abs(T_g - T_o).max() < 1e-9
+        seen5 |= so["n_after_bounds"] == 5 and so["n_inliers"] == 5
+    assert seen5
+
 def test_triangulate_bit_exact_and_analytic(api):
     from stereo_visual_odometry_amd import synthetic as syn
     Pl, Pr = syn.projection_matrices(syn.KITTI00)
