@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Generates the colour fixture of BASELINE.json configs[0] (`vo 400 run1`) from the reference's bundled data set.
 Data only — no reference source is copied:
-  * run1_bgr_{left,right}_0_15.npy.xz : stereo pairs 0..15 as the reference CLI feeds them to stereo_callback — 512x288
-    8-bit BGR, interleaved (cv::imread default, main.cpp:38-46) — an lzma-compressed .npy of shape (16, 288, 512, 3);
+  * run1_bgr_{left,right}_0_47.npy.xz : stereo pairs 0..47 as the reference CLI feeds them to stereo_callback — 512x288
+    8-bit BGR, interleaved (cv::imread default, main.cpp:38-46) — an lzma-compressed .npy of shape (48, 288, 512, 3);
   * run1_recorded.npz : ALL rows of run1/result.csv (the trajectory the reference recorded, 6 significant digits) and of
     run1/gt.csv.
 Run in the build container only (needs /root/reference): python tests/golden/make_run1_color_fixture.py
@@ -15,7 +15,7 @@ from PIL import Image
 
 REF = "/root/reference/run1"
 HERE = os.path.dirname(os.path.abspath(__file__))
-N = 16
+N = 48
 
 
 def bgr(path):
