@@ -20,10 +20,98 @@ static __device__ __forceinline__ bool seq_live(const SeqState& s) { return s.ac
 static __device__ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
 
 // ------------------------------------------------------------------------------------------------ triangulation
+// ---- the 4 x 4 SVD of the triangulation, register-resident.  jacobi_svd<4, 4> walks its row pairs with run-time indices; on
+// arrays the compiler keeps in VGPRs every such access becomes a select chain (the pair loop body was ~800 VALU instructions,
+// 430 of them v_cndmask).  Here the six pairs are six template instances with compile-time indices: the same rotations in the
+// same order with the same arithmetic (bit-identical results), ~230 instructions per pair.  Only the right singular vector of
+// the SMALLEST singular value is needed (the null vector of the DLT system), so the descending selection sort of the generic
+// routine is replayed on the four values alone to learn which row it would have moved to the last place.
+template <int I, int J>
+static __device__ __forceinline__ bool svd4_rotate(double (&At)[4][4], double (&Wv)[4], double (&Vt)[4][4]) {
+    const double eps = SVO_DBL_EPS * 10;
+    double a = Wv[I], p = 0, b = Wv[J], c, s;
+#pragma unroll
+    for (int k = 0; k < 4; k++) p += At[I][k] * At[J][k];
+    if (fabs(p) <= eps * sqrt(a * b)) return false;
+    p *= 2;
+    double beta = a - b, gamma = sqrt(p * p + beta * beta);
+    if (beta < 0) {
+        double delta = (gamma - beta) * 0.5;
+        s = sqrt(delta / gamma);
+        c = p / (gamma * s * 2);
+    } else {
+        c = sqrt((gamma + beta) / (gamma * 2));
+        s = p / (gamma * c * 2);
+    }
+    a = b = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double t0 = c * At[I][k] + s * At[J][k];
+        double t1 = -s * At[I][k] + c * At[J][k];
+        At[I][k] = t0; At[J][k] = t1;
+        a += t0 * t0; b += t1 * t1;
+    }
+    Wv[I] = a; Wv[J] = b;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double t0 = c * Vt[I][k] + s * Vt[J][k];
+        double t1 = -s * Vt[I][k] + c * Vt[J][k];
+        Vt[I][k] = t0; Vt[J][k] = t1;
+    }
+    return true;
+}
+// A: row-major 4 x 4.  X: the row of Vt that svd_rm<4, 4> would return as Vt[12..15].
+static __device__ void svd4_null_vector(const double (&A)[4][4], double (&X)[4]) {
+    double At[4][4], Vt[4][4], Wv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { At[i][j] = A[j][i]; Vt[i][j] = i == j ? 1.0 : 0.0; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sd += At[i][k] * At[i][k];
+        Wv[i] = sd;
+    }
+#pragma unroll 1
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+        changed |= svd4_rotate<0, 1>(At, Wv, Vt); changed |= svd4_rotate<0, 2>(At, Wv, Vt); changed |= svd4_rotate<0, 3>(At, Wv, Vt);
+        changed |= svd4_rotate<1, 2>(At, Wv, Vt); changed |= svd4_rotate<1, 3>(At, Wv, Vt); changed |= svd4_rotate<2, 3>(At, Wv, Vt);
+        if (!changed) break;
+    }
+    double w[4]; int p[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sd += At[i][k] * At[i][k];
+        w[i] = sqrt(sd); p[i] = i;
+    }
+    // the selection sort of jacobi_svd (descending; the FIRST maximum wins ties), replayed on (value, original row) pairs
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        int j = i; double wj = w[i];
+#pragma unroll
+        for (int k = i + 1; k < 4; k++) { const bool g = wj < w[k]; j = g ? k : j; wj = g ? w[k] : wj; }
+        const double wi = w[i]; const int pi = p[i]; int pj = p[i];
+#pragma unroll
+        for (int k = i + 1; k < 4; k++) { const bool e = j == k; pj = e ? p[k] : pj; w[k] = e ? wi : w[k]; p[k] = e ? pi : p[k]; }
+        w[i] = wj; p[i] = pj;
+    }
+    const int r = p[3];
+#pragma unroll
+    for (int c = 0; c < 4; c++) X[c] = r == 0 ? Vt[0][c] : r == 1 ? Vt[1][c] : r == 2 ? Vt[2][c] : Vt[3][c];
+}
+
 // The last block of every sequence does not triangulate: its first lane draws the RANSAC subsets (they depend on the
 // track count only), so the serial RNG walk hides under the triangulation instead of being a launch of its own.
 static __device__ void pnp_draw_subsets(const DevBuffers& d, int seq, unsigned n);
-__global__ __launch_bounds__(64) void k_triangulate(DevBuffers d) {
+// `lanes` tracks per wave: 64 when many sequences fill the GPU; 16 when a single stream runs alone — the Jacobi sweeps of a wave
+// last as long as its slowest lane needs, so with the GPU nearly empty fewer tracks per wave shorten the kernel (same results).
+__global__ __launch_bounds__(64) void k_triangulate(DevBuffers d, int lanes) {
     const int seq = blockIdx.y;
     const SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
@@ -31,25 +119,28 @@ __global__ __launch_bounds__(64) void k_triangulate(DevBuffers d) {
         if (threadIdx.x == 0) pnp_draw_subsets(d, seq, (unsigned)s.n_tracks);
         return;
     }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int)threadIdx.x >= lanes) return;
+    const int i = blockIdx.x * lanes + threadIdx.x;
     if (i >= s.n_tracks) return;
     const size_t o = (size_t)seq * d.CAP + i;
     const float2 pl = d.tl0[o], pr = d.tr0[o];
-    double A[16], Wv[4], Ut[16], Vt[16];
+    double A[4][4], V[4];
     const double xl = pl.x, yl = pl.y, xr = pr.x, yr = pr.y;
+#pragma unroll
     for (int k = 0; k < 4; k++) {
-        A[0 * 4 + k] = xl * (double)s.Pl[8 + k] - (double)s.Pl[0 + k];
-        A[1 * 4 + k] = yl * (double)s.Pl[8 + k] - (double)s.Pl[4 + k];
-        A[2 * 4 + k] = xr * (double)s.Pr[8 + k] - (double)s.Pr[0 + k];
-        A[3 * 4 + k] = yr * (double)s.Pr[8 + k] - (double)s.Pr[4 + k];
+        A[0][k] = xl * (double)s.Pl[8 + k] - (double)s.Pl[0 + k];
+        A[1][k] = yl * (double)s.Pl[8 + k] - (double)s.Pl[4 + k];
+        A[2][k] = xr * (double)s.Pr[8 + k] - (double)s.Pr[0 + k];
+        A[3][k] = yr * (double)s.Pr[8 + k] - (double)s.Pr[4 + k];
     }
-    svd_rm<4, 4>(A, Wv, Ut, Vt);
-    const float X = (float)Vt[12], Y = (float)Vt[13], Z = (float)Vt[14], Wh = (float)Vt[15];   // 4xN result is CV_32F
+    svd4_null_vector(A, V);
+    const float X = (float)V[0], Y = (float)V[1], Z = (float)V[2], Wh = (float)V[3];           // 4xN result is CV_32F
     const float scale = Wh != 0.f ? 1.f / Wh : 1.f;                                             // convertPointsFromHomogeneous
     d.world[3 * o] = X * scale; d.world[3 * o + 1] = Y * scale; d.world[3 * o + 2] = Z * scale;
 }
 void launch_triangulate(const DevBuffers& d, hipStream_t st) {
-    hipLaunchKernelGGL(k_triangulate, dim3((d.CAP + 63) / 64 + 1, d.B), dim3(64), 0, st, d);
+    const int lanes = d.B <= 8 ? 16 : 64;
+    hipLaunchKernelGGL(k_triangulate, dim3((d.CAP + lanes - 1) / lanes + 1, d.B), dim3(64), 0, st, d, lanes);
 }
 
 // ------------------------------------------------------------------------------------------------ subsets (cv::RNG, getSubset)
@@ -159,82 +250,209 @@ static __device__ bool rotate_pair12(double* At, double* Wv, double* Vt, int i, 
     return true;
 }
 
-// x = pinv(A) b (A: M x N row-major) through a cyclic one-sided Jacobi SVD; workspace ws needs N*M + N*N + N doubles
-template <int M, int N>
-static __device__ void svd_solve_ws(const double* A, const double* b, double* x, double* ws) {
-    double* Ut = ws; double* Vt = ws + N * M; double* Wv = Vt + N * N;
-    for (int i = 0; i < N; i++) for (int j = 0; j < M; j++) Ut[i * M + j] = A[j * N + i];
-    jacobi_svd<M, N>(Ut, Wv, Vt, N);
+// One-sided Jacobi SVD with RUN-TIME sizes (the same sweep order and arithmetic as jacobi_svd<M, N> in svo_linalg.hpp): the
+// three beta approximations of EPnP solve 6x4, 6x3 and 6x5 systems on three lanes of one wave — as three template instances
+// they were three code paths the wave executed one after the other; with the size in a register the lanes run ONE path together
+// and only the trip counts differ.  At: n rows of length m; Vt: n x n; Wv: n.
+static __device__ void jacobi_svd_rt(double* At, int m, int n, double* Wv, double* Vt, int n1) {
+    const double eps = SVO_DBL_EPS * 10, minval = SVO_DBL_MIN;
+    const int max_iter = m > 30 ? m : 30;
+#pragma unroll 1
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) { double t = At[i * m + k]; sd += t * t; }
+        Wv[i] = sd;
+        for (int k = 0; k < n; k++) Vt[i * n + k] = 0;
+        Vt[i * n + i] = 1;
+    }
+#pragma unroll 1
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+#pragma unroll 1
+        for (int i = 0; i < n - 1; i++)
+#pragma unroll 1
+            for (int j = i + 1; j < n; j++) {
+                double* Ai = At + i * m; double* Aj = At + j * m;
+                double a = Wv[i], p = 0, b = Wv[j], c, s;
+                for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = sqrt(p * p + beta * beta);
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+                for (int k = 0; k < m; k++) {
+                    double t0 = c * Ai[k] + s * Aj[k];
+                    double t1 = -s * Ai[k] + c * Aj[k];
+                    Ai[k] = t0; Aj[k] = t1;
+                    a += t0 * t0; b += t1 * t1;
+                }
+                Wv[i] = a; Wv[j] = b;
+                changed = true;
+                double* Vi = Vt + i * n; double* Vj = Vt + j * n;
+                for (int k = 0; k < n; k++) {
+                    double t0 = c * Vi[k] + s * Vj[k];
+                    double t1 = -s * Vi[k] + c * Vj[k];
+                    Vi[k] = t0; Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+#pragma unroll 1
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) { double t = At[i * m + k]; sd += t * t; }
+        Wv[i] = sqrt(sd);
+    }
+#pragma unroll 1
+    for (int i = 0; i < n - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < n; k++) if (Wv[j] < Wv[k]) j = k;
+        if (i != j) {
+            double t = Wv[i]; Wv[i] = Wv[j]; Wv[j] = t;
+            for (int k = 0; k < m; k++) { t = At[i * m + k]; At[i * m + k] = At[j * m + k]; At[j * m + k] = t; }
+            for (int k = 0; k < n; k++) { t = Vt[i * n + k]; Vt[i * n + k] = Vt[j * n + k]; Vt[j * n + k] = t; }
+        }
+    }
+#pragma unroll 1
+    for (int i = 0; i < n1; i++) {
+        double sd = i < n ? Wv[i] : 0;
+        double s = sd > minval ? 1 / sd : 0.;
+        for (int k = 0; k < m; k++) At[i * m + k] *= s;
+    }
+}
+
+// x = pinv(A) b for A: 6 x n (n = 3, 4, 5) on REGISTERS: the system is zero-padded to five columns so that the three beta
+// approximations run one instruction stream.  A zero row of At never rotates (p = 0 <= eps sqrt(a b) = 0), keeps its singular
+// value 0 (<= the threshold: dropped) and leaves the identity columns of Vt alone, so the n x n part is computed exactly as the
+// unpadded routine computes it, bit for bit.
+static __device__ void svd_solve6_reg(const double* A, int n, const double* b, double* x) {
+    constexpr int M = 6, N = 5;
+    double At[N][M], Wv[N], Vt[N][N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+        for (int j = 0; j < M; j++) At[i][j] = i < n ? A[j * n + i] : 0.0;
+    }
+    jacobi_svd_reg<M, N>(At, Wv, Vt, true);
     double thr = 0;
+#pragma unroll
     for (int i = 0; i < N; i++) thr += Wv[i];
     thr *= SVO_DBL_EPS * 2;
-    for (int k = 0; k < N; k++) x[k] = 0;
+    double xx[N] = {0, 0, 0, 0, 0};
+#pragma unroll
     for (int i = 0; i < N; i++) {
+        if (Wv[i] <= thr) continue;
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) s += At[i][k] * b[k];
+        s /= Wv[i];
+#pragma unroll
+        for (int k = 0; k < N; k++) xx[k] += s * Vt[i][k];
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) if (k < n) x[k] = xx[k];
+}
+
+// x = pinv(A) b (A: 6 x n row-major, n <= 5) through that SVD; workspace ws needs n*6 + n*n + n <= 60 doubles
+static __device__ void svd_solve6_rt(const double* A, int n, const double* b, double* x, double* ws) {
+    const int M = 6;
+    double* Ut = ws; double* Vt = ws + n * M; double* Wv = Vt + n * n;
+    for (int i = 0; i < n; i++) for (int j = 0; j < M; j++) Ut[i * M + j] = A[j * n + i];
+    jacobi_svd_rt(Ut, M, n, Wv, Vt, n);
+    double thr = 0;
+    for (int i = 0; i < n; i++) thr += Wv[i];
+    thr *= SVO_DBL_EPS * 2;
+    for (int k = 0; k < n; k++) x[k] = 0;
+    for (int i = 0; i < n; i++) {
         if (Wv[i] <= thr) continue;
         double s = 0;
         for (int k = 0; k < M; k++) s += Ut[i * M + k] * b[k];
         s /= Wv[i];
-        for (int k = 0; k < N; k++) x[k] += s * Vt[i * N + k];
+        for (int k = 0; k < n; k++) x[k] += s * Vt[i * n + k];
     }
 }
 
-// Householder QR least squares for the 6 x 4 Gauss-Newton step; everything in the workspace (A 24, b 6, x 4, A1 4, A2 4)
-static __device__ bool qr_solve64(double* A, double* b, double* x, double* A1, double* A2) {
-    const int M = 6, N = 4;
-#pragma unroll 1
+// Householder QR least squares for the 6 x 4 Gauss-Newton step, on registers with compile-time indices (the arithmetic and its
+// order are those of qr_solve<6, 4> in svo_linalg.hpp)
+static __device__ __forceinline__ bool qr_solve64_reg(double (&A)[6][4], double (&b)[6], double (&x)[4]) {
+    constexpr int M = 6, N = 4;
+    double A1[N], A2[N];
+#pragma unroll
     for (int k = 0; k < N; k++) {
         double eta = 0;
-        for (int i = k; i < M; i++) { double e = fabs(A[i * N + k]); if (eta < e) eta = e; }
+#pragma unroll
+        for (int i = k; i < M; i++) { double e = fabs(A[i][k]); if (eta < e) eta = e; }
         if (eta == 0) return false;
         double sum2 = 0, inv_eta = 1. / eta;
-        for (int i = k; i < M; i++) { A[i * N + k] *= inv_eta; sum2 += A[i * N + k] * A[i * N + k]; }
+#pragma unroll
+        for (int i = k; i < M; i++) { A[i][k] *= inv_eta; sum2 += A[i][k] * A[i][k]; }
         double sigma = sqrt(sum2);
-        if (A[k * N + k] < 0) sigma = -sigma;
-        A[k * N + k] += sigma;
-        A1[k] = sigma * A[k * N + k];
+        if (A[k][k] < 0) sigma = -sigma;
+        A[k][k] += sigma;
+        A1[k] = sigma * A[k][k];
         A2[k] = -eta * sigma;
+#pragma unroll
         for (int j = k + 1; j < N; j++) {
             double sum = 0;
-            for (int i = k; i < M; i++) sum += A[i * N + k] * A[i * N + j];
+#pragma unroll
+            for (int i = k; i < M; i++) sum += A[i][k] * A[i][j];
             double tau = sum / A1[k];
-            for (int i = k; i < M; i++) A[i * N + j] -= tau * A[i * N + k];
+#pragma unroll
+            for (int i = k; i < M; i++) A[i][j] -= tau * A[i][k];
         }
     }
+#pragma unroll
     for (int j = 0; j < N; j++) {
         double tau = 0;
-        for (int i = j; i < M; i++) tau += A[i * N + j] * b[i];
+#pragma unroll
+        for (int i = j; i < M; i++) tau += A[i][j] * b[i];
         tau /= A1[j];
-        for (int i = j; i < M; i++) b[i] -= tau * A[i * N + j];
+#pragma unroll
+        for (int i = j; i < M; i++) b[i] -= tau * A[i][j];
     }
     x[N - 1] = b[N - 1] / A2[N - 1];
+#pragma unroll
     for (int i = N - 2; i >= 0; i--) {
         double sum = 0;
-        for (int j = i + 1; j < N; j++) sum += A[i * N + j] * x[j];
+#pragma unroll
+        for (int j = i + 1; j < N; j++) sum += A[i][j] * x[j];
         x[i] = (b[i] - sum) / A2[i];
     }
     return true;
 }
 
 static __device__ void epnp_gauss_newton(const double* L, const double* rho, double* betas, double* ws) {
-    double* A = ws; double* B = ws + 24; double* X = ws + 30; double* A1 = ws + 34; double* A2 = ws + 38;
+    (void)ws;
+    double bt[4] = {betas[0], betas[1], betas[2], betas[3]};
 #pragma unroll 1
     for (int it = 0; it < 5; it++) {
-        const double b0 = betas[0], b1 = betas[1], b2 = betas[2], b3 = betas[3];
-#pragma unroll 1
+        const double b0 = bt[0], b1 = bt[1], b2 = bt[2], b3 = bt[3];
+        double A[6][4], B[6], X[4];
+#pragma unroll
         for (int i = 0; i < 6; i++) {
-            const double* rl = L + 10 * i; double* ra = A + 4 * i;
-            ra[0] = 2 * rl[0] * b0 + rl[1] * b1 + rl[3] * b2 + rl[6] * b3;
-            ra[1] = rl[1] * b0 + 2 * rl[2] * b1 + rl[4] * b2 + rl[7] * b3;
-            ra[2] = rl[3] * b0 + rl[4] * b1 + 2 * rl[5] * b2 + rl[8] * b3;
-            ra[3] = rl[6] * b0 + rl[7] * b1 + rl[8] * b2 + 2 * rl[9] * b3;
+            const double* rl = L + 10 * i;
+            A[i][0] = 2 * rl[0] * b0 + rl[1] * b1 + rl[3] * b2 + rl[6] * b3;
+            A[i][1] = rl[1] * b0 + 2 * rl[2] * b1 + rl[4] * b2 + rl[7] * b3;
+            A[i][2] = rl[3] * b0 + rl[4] * b1 + 2 * rl[5] * b2 + rl[8] * b3;
+            A[i][3] = rl[6] * b0 + rl[7] * b1 + rl[8] * b2 + 2 * rl[9] * b3;
             B[i] = rho[i] - (rl[0] * b0 * b0 + rl[1] * b0 * b1 + rl[2] * b1 * b1 +
                              rl[3] * b0 * b2 + rl[4] * b1 * b2 + rl[5] * b2 * b2 +
                              rl[6] * b0 * b3 + rl[7] * b1 * b3 + rl[8] * b2 * b3 +
                              rl[9] * b3 * b3);
         }
-        if (!qr_solve64(A, B, X, A1, A2)) return;
-        for (int i = 0; i < 4; i++) betas[i] += X[i];
+        if (!qr_solve64_reg(A, B, X)) break;
+#pragma unroll
+        for (int i = 0; i < 4; i++) bt[i] += X[i];
     }
+#pragma unroll
+    for (int i = 0; i < 4; i++) betas[i] = bt[i];
 }
 
 // compute_ccs, compute_pcs, solve_for_sign, estimate_R_and_t (Arun / Horn), reprojection_error.  ws: >= 66 doubles.
@@ -270,8 +488,7 @@ static __device__ double epnp_compute_R_and_t(const double* ar, const double* be
             abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
         }
     }
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ut[i * 3 + j] = abt[j * 3 + i];
-    jacobi_svd<3, 3>(Ut, Wv, Vt, 3);
+    svd_rm<3, 3>(abt, Wv, Ut, Vt);                                     // register form (svo_linalg.hpp)
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
         double s = 0;
         for (int k = 0; k < 3; k++) s += Ut[k * 3 + i] * Vt[k * 3 + j];
@@ -406,21 +623,24 @@ static __device__ void epnp_branch(double* ar, int branch, double fu, double fv,
     const double* L = ar + EA_L; const double* rho = ar + EA_RHO;
     double* ws = ar + EA_BR + (branch - 1) * EA_BRSZ;
     double* Lx = ws + 70; double* bx = ws + 100; double* be = ws + 106;       // svd workspace occupies ws[0, 60)
+    // the columns of L each approximation keeps (epnp.cpp find_betas_approx_1 / _2 / _3) and how many
+    const int N = branch == 1 ? 4 : branch == 2 ? 3 : 5;
+    const int c3 = branch == 1 ? 6 : 3, c2 = branch == 1 ? 3 : 2;
+    for (int i = 0; i < 6; i++) {
+        Lx[N * i] = L[10 * i]; Lx[N * i + 1] = L[10 * i + 1]; Lx[N * i + 2] = L[10 * i + c2];
+        if (N > 3) Lx[N * i + 3] = L[10 * i + c3];
+        if (N > 4) Lx[N * i + 4] = L[10 * i + 4];
+    }
+    svd_solve6_reg(Lx, N, rho, bx);                                   // ONE code path for the three lanes, on registers
     if (branch == 1) {
-        for (int i = 0; i < 6; i++) { Lx[4 * i] = L[10 * i]; Lx[4 * i + 1] = L[10 * i + 1]; Lx[4 * i + 2] = L[10 * i + 3]; Lx[4 * i + 3] = L[10 * i + 6]; }
-        svd_solve_ws<6, 4>(Lx, rho, bx, ws);
         if (bx[0] < 0) { be[0] = sqrt(-bx[0]); be[1] = -bx[1] / be[0]; be[2] = -bx[2] / be[0]; be[3] = -bx[3] / be[0]; }
         else { be[0] = sqrt(bx[0]); be[1] = bx[1] / be[0]; be[2] = bx[2] / be[0]; be[3] = bx[3] / be[0]; }
     } else if (branch == 2) {
-        for (int i = 0; i < 6; i++) { Lx[3 * i] = L[10 * i]; Lx[3 * i + 1] = L[10 * i + 1]; Lx[3 * i + 2] = L[10 * i + 2]; }
-        svd_solve_ws<6, 3>(Lx, rho, bx, ws);
         if (bx[0] < 0) { be[0] = sqrt(-bx[0]); be[1] = (bx[2] < 0) ? sqrt(-bx[2]) : 0.0; }
         else { be[0] = sqrt(bx[0]); be[1] = (bx[2] > 0) ? sqrt(bx[2]) : 0.0; }
         if (bx[1] < 0) be[0] = -be[0];
         be[2] = 0.0; be[3] = 0.0;
     } else {
-        for (int i = 0; i < 6; i++) for (int j = 0; j < 5; j++) Lx[5 * i + j] = L[10 * i + j];
-        svd_solve_ws<6, 5>(Lx, rho, bx, ws);
         if (bx[0] < 0) { be[0] = sqrt(-bx[0]); be[1] = (bx[2] < 0) ? sqrt(-bx[2]) : 0.0; }
         else { be[0] = sqrt(bx[0]); be[1] = (bx[2] > 0) ? sqrt(bx[2]) : 0.0; }
         if (bx[1] < 0) be[0] = -be[0];
@@ -551,17 +771,35 @@ static __device__ int ransac_update_num_iters(double p, double ep, int model_poi
 
 // Cholesky solve of a 6x6 SPD system (the damped normal equations of the LM step)
 static __device__ void chol_solve6(const double* A, const double* b, double* x) {
-    double Lm[36];
-    for (int i = 0; i < 6; i++)
+    double Lm[6][6];                                                  // every index below is a compile-time constant: registers
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
         for (int j = 0; j <= i; j++) {
             double s = A[6 * i + j];
-            for (int k = 0; k < j; k++) s -= Lm[6 * i + k] * Lm[6 * j + k];
-            if (i == j) Lm[6 * i + i] = sqrt(s > 1e-300 ? s : 1e-300);
-            else Lm[6 * i + j] = s / Lm[6 * j + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= Lm[i][k] * Lm[j][k];
+            if (i == j) Lm[i][i] = sqrt(s > 1e-300 ? s : 1e-300);
+            else Lm[i][j] = s / Lm[j][j];
         }
-    double y[6];
-    for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= Lm[6 * i + k] * y[k]; y[i] = s / Lm[6 * i + i]; }
-    for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= Lm[6 * k + i] * x[k]; x[i] = s / Lm[6 * i + i]; }
+    }
+    double y[6], xx[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= Lm[i][k] * y[k];
+        y[i] = s / Lm[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) s -= Lm[k][i] * xx[k];
+        xx[i] = s / Lm[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = xx[i];
 }
 
 // After the first chunk: run the accept / shrink rule over its counts and publish how many iterations the serial loop
@@ -731,30 +969,42 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
         sh.lambdaLg10 = -3; sh.iters = 0; sh.state = 0; sh.mode = direct ? 2 : 1; sh.prevErrNorm = 0; sh.lambda_tab = d.lm_lambda;
     }
     __syncthreads();
+    // CvLevMarq's state machine (CALC_J -> step -> CHECK_ERR -> accept / raise lambda), with one change of SCHEDULE only: every
+    // evaluation of a trial point computes the Jacobian sums together with the error, so an accepted step (the normal case)
+    // already has J for the next CALC_J instead of re-evaluating the same point — half the evaluations, the same numbers.
+    // sh.mode: 1 = the evaluation to come is the very first (at the start point), 0 = it is of a trial point, 2 = finished.
     for (int guard = 0; guard < 1000; guard++) {
         const int mode = sh.mode;
         if (mode == 2) break;
-        lm_eval(d, s, o, n, mode == 1, sh);
+        lm_eval(d, s, o, n, true, sh);
         if (threadIdx.x == 0) {
-            if (mode == 1) {                               // CALC_J: J and err at param are ready
-                int q = 0;
-                for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { sh.JtJ[6 * a + b] = sh.JtJ[6 * b + a] = sh.red[0][q++]; }
-                for (int a = 0; a < 6; a++) sh.JtErr[a] = sh.red[0][21 + a];
-                for (int a = 0; a < 6; a++) sh.prev[a] = sh.param[a];
-                lm_step(sh);
-                if (sh.iters == 0) sh.prevErrNorm = sqrt(sh.red[0][27]);
-                sh.mode = 0;
-            } else {                                       // CHECK_ERR
-                double errNorm = sqrt(sh.red[0][27]);
+            bool take_J = false;
+            if (mode == 1) {                               // CALC_J at the start point
+                sh.prevErrNorm = sqrt(sh.red[0][27]);
+                take_J = true;
+            } else {                                       // CHECK_ERR at the trial point
+                const double errNorm = sqrt(sh.red[0][27]);
                 if (errNorm > sh.prevErrNorm && ++sh.lambdaLg10 <= 16) {
-                    lm_step(sh);
+                    lm_step(sh);                           // same J, same start, stronger damping
                 } else {
                     sh.lambdaLg10 = sh.lambdaLg10 - 1 > -16 ? sh.lambdaLg10 - 1 : -16;
                     double dn = 0, pn = 0;
                     for (int a = 0; a < 6; a++) { dn += (sh.param[a] - sh.prev[a]) * (sh.param[a] - sh.prev[a]); pn += sh.prev[a] * sh.prev[a]; }
                     if (++sh.iters >= 20 || sqrt(dn) / (sqrt(pn) + SVO_DBL_EPS) < 1.1920928955078125e-07) sh.mode = 2;
-                    else { sh.prevErrNorm = errNorm; sh.mode = 1; }
+                    else { sh.prevErrNorm = errNorm; take_J = true; }
                 }
+            }
+            if (take_J) {                                  // CALC_J: J and err at param are ready -> step
+                int q = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int b = a; b < 6; b++) { sh.JtJ[6 * a + b] = sh.JtJ[6 * b + a] = sh.red[0][q++]; }
+                }
+                for (int a = 0; a < 6; a++) sh.JtErr[a] = sh.red[0][21 + a];
+                for (int a = 0; a < 6; a++) sh.prev[a] = sh.param[a];
+                lm_step(sh);
+                sh.mode = 0;
             }
         }
         __syncthreads();

@@ -87,11 +87,122 @@ __device__ void jacobi_svd(PA At, PW Wv, PA Vt, int n1) {
     }
 }
 
+// The same algorithm on REGISTER arrays with every index a compile-time constant (all loops over rows / pairs unrolled; only the
+// sweep loop is dynamic).  jacobi_svd above walks its row pairs with run-time indices: on private arrays that turns every
+// access into a select chain or a scratch access, in LDS into a dependent ds_read.  This form executes the same rotations in the
+// same order with the same arithmetic — bit-identical results — in a fraction of the instructions, for the small fixed sizes the
+// geometry kernels solve over and over (3 x 3, 4 x 4, 6 x 5).  The selection sort is replayed with predicated row swaps.
+template <int M, int N>
+__device__ __forceinline__ void jacobi_svd_reg(double (&At)[N][M], double (&Wv)[N], double (&Vt)[N][N], bool normalize) {
+    const double eps = SVO_DBL_EPS * 10, minval = SVO_DBL_MIN;
+    constexpr int max_iter = M > 30 ? M : 30;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) sd += At[i][k] * At[i][k];
+        Wv[i] = sd;
+#pragma unroll
+        for (int k = 0; k < N; k++) Vt[i][k] = i == k ? 1.0 : 0.0;
+    }
+#pragma unroll 1
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) {
+#pragma unroll
+            for (int j = i + 1; j < N; j++) {
+                double a = Wv[i], p = 0, b = Wv[j], c, s;
+#pragma unroll
+                for (int k = 0; k < M; k++) p += At[i][k] * At[j][k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = sqrt(p * p + beta * beta);
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+#pragma unroll
+                for (int k = 0; k < M; k++) {
+                    double t0 = c * At[i][k] + s * At[j][k];
+                    double t1 = -s * At[i][k] + c * At[j][k];
+                    At[i][k] = t0; At[j][k] = t1;
+                    a += t0 * t0; b += t1 * t1;
+                }
+                Wv[i] = a; Wv[j] = b;
+                changed = true;
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    double t0 = c * Vt[i][k] + s * Vt[j][k];
+                    double t1 = -s * Vt[i][k] + c * Vt[j][k];
+                    Vt[i][k] = t0; Vt[j][k] = t1;
+                }
+            }
+        }
+        if (!changed) break;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) sd += At[i][k] * At[i][k];
+        Wv[i] = sqrt(sd);
+    }
+    // selection sort, descending, the first maximum wins ties: row i <-> row j with j found at run time, applied as predicated swaps
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+        int j = i; double wj = Wv[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++) { const bool g = wj < Wv[k]; j = g ? k : j; wj = g ? Wv[k] : wj; }
+#pragma unroll
+        for (int k = i + 1; k < N; k++) {
+            const bool e = j == k;
+            { const double x = Wv[i], y = Wv[k]; Wv[i] = e ? y : x; Wv[k] = e ? x : y; }
+#pragma unroll
+            for (int c = 0; c < M; c++) { const double x = At[i][c], y = At[k][c]; At[i][c] = e ? y : x; At[k][c] = e ? x : y; }
+#pragma unroll
+            for (int c = 0; c < N; c++) { const double x = Vt[i][c], y = Vt[k][c]; Vt[i][c] = e ? y : x; Vt[k][c] = e ? x : y; }
+        }
+    }
+    if (normalize) {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const double sd = Wv[i];
+            const double s = sd > minval ? 1 / sd : 0.;
+#pragma unroll
+            for (int k = 0; k < M; k++) At[i][k] *= s;
+        }
+    }
+}
+
 // SVD of a row-major M x N matrix A.  Ut: N x M, Vt: N x N.
 template <int M, int N>
 __device__ void svd_rm(const double* A, double* Wv, double* Ut, double* Vt) {
-    for (int i = 0; i < N; i++) for (int j = 0; j < M; j++) Ut[i * M + j] = A[j * N + i];
-    jacobi_svd<M, N>(Ut, Wv, Vt, N);
+    if constexpr (M <= 4 && N <= 4) {                                // small: the register form (bit-identical, far fewer instructions)
+        double At[N][M], W[N], V[N][N];
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+#pragma unroll
+            for (int j = 0; j < M; j++) At[i][j] = A[j * N + i];
+        }
+        jacobi_svd_reg<M, N>(At, W, V, true);
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            Wv[i] = W[i];
+#pragma unroll
+            for (int j = 0; j < M; j++) Ut[i * M + j] = At[i][j];
+#pragma unroll
+            for (int j = 0; j < N; j++) Vt[i * N + j] = V[i][j];
+        }
+    } else {
+        for (int i = 0; i < N; i++) for (int j = 0; j < M; j++) Ut[i * M + j] = A[j * N + i];
+        jacobi_svd<M, N>(Ut, Wv, Vt, N);
+    }
 }
 
 // x = pinv(A) b by SVD back-substitution; singular values <= 2*eps*sum(w) are dropped.
@@ -175,6 +286,7 @@ __device__ inline void rodrigues_to_matrix(const double r[3], double R[9], doubl
     double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
     double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
     const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
     for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
     if (J) {
         double drrt[27] = {rx + rx, ry, rz, ry, 0, 0, rz, 0, 0,
@@ -183,10 +295,12 @@ __device__ inline void rodrigues_to_matrix(const double r[3], double R[9], doubl
         const double d_r_x_[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0,
                                    0, 0, 1, 0, 0, 0, -1, 0, 0,
                                    0, -1, 0, 1, 0, 0, 0, 0, 0};
+#pragma unroll
         for (int i = 0; i < 3; i++) {
             double ri = i == 0 ? rx : i == 1 ? ry : rz;
             double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
             double a3 = (c - s * itheta) * ri, a4 = s * itheta;
+#pragma unroll
             for (int k = 0; k < 9; k++)
                 J[i * 9 + k] = a0 * I[k] + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * r_x[k] + a4 * d_r_x_[i * 9 + k];
         }
