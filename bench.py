@@ -166,6 +166,7 @@ def main():
         return lp, rp
 
     Pl, Pr = syn.projection_matrices(cal)
+    os.environ.setdefault("SVO_GRAPH", "0")      # the roofline needs the LK kernel's own HIP events: launch-list mode even for tiny --seqs
     vos = []
     for c in range(C):
         v = api.BatchVisualOdometry(W, H, Bc, api.default_config(**over), device=local_rank)

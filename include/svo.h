@@ -127,7 +127,10 @@ int svo_collect(svo_context* ctx, double* T_out, int* ok_out, svo_frame_stats* s
 int svo_get_features(svo_context* ctx, int seq, int cap, float* xy, int* ages, int* strengths);
 int svo_get_last_tracks(svo_context* ctx, int seq, int cap, float* pl0, float* pr0, float* pl1, float* pr1,
                         float* world, uint8_t* inlier);
-/* Timing: HIP-event milliseconds of the dominant kernel (the fused LK chain) in the last processed frame, and of the whole frame. */
+/* Timing: HIP-event milliseconds of the dominant kernel (the fused LK chain) in the last processed frame, and of the whole frame.
+ * With SVO_GRAPH=1 in the environment a context replays each frame as a captured hipGraph (one per results-ring slot; off by
+ * default: measured slightly slower than the launch list on MI355X): stage events are then not recorded and lk_ms /
+ * svo_get_stage_timing fail with SVO_ERR_STATE; frame_ms is always available. */
 int svo_get_last_timing(svo_context* ctx, float* lk_ms, float* frame_ms);
 /* Per-stage HIP-event milliseconds of the last collected frame (all sequences of the context together), in pipeline order:
  * ms[0] ingest + pyramids (vo.cpp:74-75, 200-201)   ms[1] FAST + bucketing, both passes (vo.cpp:325-332)

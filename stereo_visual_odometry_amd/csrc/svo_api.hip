@@ -78,6 +78,12 @@ struct svo_context {
     bool projection_set = false;
     int lk_grid = 0;
     int lk_hint = 0;                             // feature count seen in the last collected frame (sizes the LK grid; 0 = unknown)
+    // hipGraph replay of the frame's launch list (one executable graph per results-ring slot: the slot fixes the pointer table,
+    // the result record and the copies; re-captured when the stride or the LK grid size changes)
+    bool use_graph = false;
+    hipGraphExec_t gexec[SVO_RING] = {};
+    int g_stride[SVO_RING] = {}, g_gn[SVO_RING] = {};
+    bool staged_slot[SVO_RING] = {};             // the slot's stage events were recorded (launch-list mode only)
 };
 
 template <typename T>
@@ -173,6 +179,13 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     }
     HIPCHK(hipMemcpyAsync(d.st, hs.data(), sizeof(SeqState) * B, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    {
+        // SVO_GRAPH=1 replays every frame as a captured hipGraph.  Measured on MI355X, one sequence, synchronous, host images
+        // (scratch/graph_ab.py, same box): 0.718 ms per frame pair with the launch list, 0.737 ms with the graph — the ~25 launches
+        // are issued ahead of the GPU anyway and the graph's dispatch is not cheaper on this runtime — so the launch list stays
+        // the default and the graph is the option.
+        c->use_graph = e ? atoi(e) != 0 : false;
+    }
     undo.c = nullptr;
     *out = c;
     return SVO_OK;
@@ -200,6 +213,7 @@ extern "C" void svo_destroy(svo_context* c) {
         if (c->ev_pyr[i]) (void)hipEventDestroy(c->ev_pyr[i]);
         if (c->ev_tri[i]) (void)hipEventDestroy(c->ev_tri[i]);
     }
+    for (int i = 0; i < SVO_RING; i++) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -231,6 +245,33 @@ extern "C" int svo_set_projection(svo_context* c, int seq, const float Pl[12], c
 static int stage_host_images(svo_context* c, const uint8_t* const* left, const uint8_t* const* right, int stride,
                              std::vector<const uint8_t*>& lp, std::vector<const uint8_t*>& rp);
 
+// The launch list of one frame (vo.cpp:41-137 as kernels), between the pointer-table upload and the result download.
+// with_events: record the stage-boundary events (not inside a graph capture).
+static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_events) {
+    DevBuffers& d = c->d;
+    const int B = d.B;
+    hipStream_t s = c->stream;
+    const uint8_t** hp = c->h_ptrs + (size_t)slot * 2 * B;
+    const uint8_t** dp = d.img_ptrs + (size_t)slot * 2 * B;
+    HIPCHK(hipMemcpyAsync((void*)dp, (const void*)hp, sizeof(uint8_t*) * 2 * B, hipMemcpyHostToDevice, s));
+    launch_frame_begin(d, s);
+    launch_ingest(d, dp, stride, s);
+    launch_pyramid(d, s);
+    if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
+    launch_detect(d, 0, -1, s);
+    launch_detect(d, 1, -1, s);
+    if (with_events) HIPCHK(hipEventRecord(c->ev_lk0[slot], s));
+    launch_lk_chain(d, gn, s);
+    if (with_events) HIPCHK(hipEventRecord(c->ev_lk1[slot], s));
+    launch_compact(d, s);
+    launch_triangulate(d, s);
+    if (with_events) HIPCHK(hipEventRecord(c->ev_tri[slot], s));
+    launch_pnp(d, s);
+    launch_frame_end(d, slot, s);
+    HIPCHK(hipMemcpyAsync(c->h_results + (size_t)slot * B, d.results + (size_t)slot * B, sizeof(FrameResult) * B, hipMemcpyDeviceToHost, s));
+    return SVO_OK;
+}
+
 // Enqueue one frame for all sequences.  ptrs: host array [2][B] of DEVICE image pointers.
 static int enqueue_frame(svo_context* c, const uint8_t* const* left_dev, const uint8_t* const* right_dev, int stride) {
     if (c->inflight >= SVO_RING) { g_err = "too many frames in flight (collect first)"; return SVO_ERR_STATE; }
@@ -238,30 +279,36 @@ static int enqueue_frame(svo_context* c, const uint8_t* const* left_dev, const u
     const int slot = c->head, B = d.B;
     const uint8_t** hp = c->h_ptrs + (size_t)slot * 2 * B;
     for (int i = 0; i < B; i++) { hp[i] = left_dev[i]; hp[B + i] = right_dev[i]; }
-    const uint8_t** dp = d.img_ptrs + (size_t)slot * 2 * B;
     hipStream_t s = c->stream;
-    HIPCHK(hipEventRecord(c->ev_f0[slot], s));
-    HIPCHK(hipMemcpyAsync((void*)dp, (const void*)hp, sizeof(uint8_t*) * 2 * B, hipMemcpyHostToDevice, s));
-    launch_frame_begin(d, s);
-    launch_ingest(d, dp, stride, s);
-    launch_pyramid(d, s);
-    HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
-    launch_detect(d, 0, -1, s);
-    launch_detect(d, 1, -1, s);
-    HIPCHK(hipEventRecord(c->ev_lk0[slot], s));
-    // grid sized from the last feature counts the host has seen (+30 %); the kernel strides, so an underestimate is only slower
-    {
-        int gn = c->lk_grid;
-        if (c->lk_hint > 0) { int h = c->lk_hint + c->lk_hint / 3 + 64; if (h < gn) gn = h; }
-        launch_lk_chain(d, gn, s);
+    // LK grid sized from the last feature counts the host has seen (+30 %); the kernel strides, so an underestimate is only slower
+    int gn = c->lk_grid;
+    if (c->lk_hint > 0) {
+        int h = c->lk_hint + c->lk_hint / 3 + 64;
+        if (c->use_graph) h = (h + 511) / 512 * 512;                 // coarse steps: the graph is re-captured when this changes
+        if (h < gn) gn = h;
     }
-    HIPCHK(hipEventRecord(c->ev_lk1[slot], s));
-    launch_compact(d, s);
-    launch_triangulate(d, s);
-    HIPCHK(hipEventRecord(c->ev_tri[slot], s));
-    launch_pnp(d, s);
-    launch_frame_end(d, slot, s);
-    HIPCHK(hipMemcpyAsync(c->h_results + (size_t)slot * B, d.results + (size_t)slot * B, sizeof(FrameResult) * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(c->ev_f0[slot], s));
+    bool replayed = false;
+    if (c->use_graph) {
+        if (!c->gexec[slot] || c->g_stride[slot] != stride || c->g_gn[slot] != gn) {
+            if (c->gexec[slot]) { (void)hipGraphExecDestroy(c->gexec[slot]); c->gexec[slot] = nullptr; }
+            hipGraph_t g = nullptr;
+            bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                const int rc = issue_frame(c, slot, stride, gn, false);
+                ok = (hipStreamEndCapture(s, &g) == hipSuccess) && rc == SVO_OK && g;
+            }
+            if (ok) ok = hipGraphInstantiate(&c->gexec[slot], g, nullptr, nullptr, 0) == hipSuccess;
+            if (g) (void)hipGraphDestroy(g);
+            if (!ok) {                                                // capture is an optimisation: without it the same launches are issued directly
+                (void)hipGetLastError();
+                c->gexec[slot] = nullptr; c->use_graph = false;
+            } else { c->g_stride[slot] = stride; c->g_gn[slot] = gn; }
+        }
+        if (c->use_graph) { HIPCHK(hipGraphLaunch(c->gexec[slot], s)); replayed = true; }
+    }
+    if (!replayed) { const int rc = issue_frame(c, slot, stride, gn, true); if (rc != SVO_OK) return rc; }
+    c->staged_slot[slot] = !replayed;
     HIPCHK(hipEventRecord(c->ev_done[slot], s));
     HIPCHK(hipGetLastError());
     c->head = (c->head + 1) % SVO_RING; c->inflight++;
@@ -406,7 +453,10 @@ extern "C" int svo_get_last_timing(svo_context* c, float* lk_ms, float* frame_ms
     if (!c || c->last_slot < 0) return fail_arg("no frame collected yet");
     HIPCHK(hipSetDevice(c->device));
     const int s = c->last_slot;
-    if (lk_ms) HIPCHK(hipEventElapsedTime(lk_ms, c->ev_lk0[s], c->ev_lk1[s]));
+    if (lk_ms) {
+        if (!c->staged_slot[s]) { g_err = "stage events are not recorded while frames are replayed as a hipGraph (SVO_GRAPH=0)"; return SVO_ERR_STATE; }
+        HIPCHK(hipEventElapsedTime(lk_ms, c->ev_lk0[s], c->ev_lk1[s]));
+    }
     if (frame_ms) HIPCHK(hipEventElapsedTime(frame_ms, c->ev_f0[s], c->ev_done[s]));
     return SVO_OK;
 }
@@ -415,6 +465,7 @@ extern "C" int svo_get_stage_timing(svo_context* c, float ms[5]) {
     if (!c || !ms || c->last_slot < 0) return fail_arg("no frame collected yet");
     HIPCHK(hipSetDevice(c->device));
     const int s = c->last_slot;
+    if (!c->staged_slot[s]) { g_err = "stage events are not recorded while frames are replayed as a hipGraph (SVO_GRAPH=0)"; return SVO_ERR_STATE; }
     hipEvent_t ev[6] = {c->ev_f0[s], c->ev_pyr[s], c->ev_lk0[s], c->ev_lk1[s], c->ev_tri[s], c->ev_done[s]};
     for (int i = 0; i < 5; i++) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
     return SVO_OK;

@@ -127,8 +127,9 @@ def test_identical_frames_give_identity_motion(api):
     assert ok and np.abs(T - np.eye(4)).max() < 1e-3
 
 
-def test_timing_and_stream_accessors(api):
+def test_timing_and_stream_accessors(api, monkeypatch):
     from stereo_visual_odometry_amd import synthetic as syn
+    monkeypatch.setenv("SVO_GRAPH", "0")                             # stage events exist in launch-list mode
     seq, cal = small_seq(n=2)
     vo = api.BatchVisualOdometry(320, 160, 1, api.default_config(max_translation_norm=2.0))
     vo.initalize_projection_matricies(*syn.projection_matrices(cal))
@@ -140,6 +141,42 @@ def test_timing_and_stream_accessors(api):
     st = vo.stage_timing()                                            # svo_get_stage_timing: the five stages tile the frame
     assert list(st) == list(vo.STAGES) and all(v > 0 for v in st.values())
     assert abs(st["lk"] - lk) < 1e-3 and abs(sum(st.values()) - fr) < 0.05 * fr
+
+
+def test_graph_replay_equals_the_launch_list(api, monkeypatch):
+    """Small contexts replay each frame as a captured hipGraph (one per results-ring slot).  Same kernels, same order: poses,
+    counters and feature sets are identical to the launch list, frame after frame (more frames than ring slots, so graphs are
+    re-launched, and a host-image stride change forces a re-capture); only the stage timers are unavailable."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    seq, cal = small_seq(n=12, seed=8)
+    P = syn.projection_matrices(cal)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SVO_GRAPH", mode)
+        vo = api.VisualOdometry(cfg=api.default_config(max_translation_norm=2.0)); vo.initalize_projection_matricies(*P)
+        res = []
+        for k in range(12):
+            L, R = seq.left[k], seq.right[k]
+            if k >= 9:                                                # a wider buffer: another row stride
+                Lw = np.zeros((L.shape[0], L.shape[1] + 16), np.uint8); Lw[:, :L.shape[1]] = L
+                Rw = np.zeros_like(Lw); Rw[:, :R.shape[1]] = R
+                T = np.zeros(16); st = api.SvoFrameStats()
+                rc = api.check(api.lib.svo_process(vo._h, api.ptr(Lw), api.ptr(Rw), Lw.shape[1], api.ptr(T), C.byref(st)))
+                ok, T, stats = bool(rc), T.reshape(4, 4), st.as_dict()
+            else:
+                ok, T = vo.stereo_callback(L, R); stats = vo.stats.as_dict()
+            res.append((ok, T.copy(), stats, vo.features()[0].copy()))
+        if mode == "1":
+            with pytest.raises(api._lib.SvoError):
+                vo.stage_timing()
+            lk = C.c_float(0); fr = C.c_float(0)
+            assert api.lib.svo_get_last_timing(vo._h, None, C.byref(fr)) == 0 and fr.value > 0      # the whole-frame time is always there
+        else:
+            assert all(v > 0 for v in vo.stage_timing().values())
+        outs[mode] = res
+    for a, b in zip(outs["1"], outs["0"]):
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3])
+    assert sum(r[0] for r in outs["1"]) >= 9
 
 
 def test_set_projection_per_sequence_and_all(api):
