@@ -184,6 +184,7 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
         // (scratch/graph_ab.py, same box): 0.718 ms per frame pair with the launch list, 0.737 ms with the graph — the ~25 launches
         // are issued ahead of the GPU anyway and the graph's dispatch is not cheaper on this runtime — so the launch list stays
         // the default and the graph is the option.
+        const char* e = getenv("SVO_GRAPH");
         c->use_graph = e ? atoi(e) != 0 : false;
     }
     undo.c = nullptr;
