@@ -159,10 +159,13 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
         HIPCHK(hipStreamSynchronize(c->stream));                          // h is a stack array
         d.lm_lambda = lam;
     }
-    ALLOC(d.results, (size_t)SVO_RING * B);
     ALLOC(d.img_ptrs, (size_t)SVO_RING * 2 * B);
 #undef ALLOC
-    HIPCHK(hipHostMalloc((void**)&c->h_results, sizeof(FrameResult) * SVO_RING * B));
+    // the results ring lives in pinned HOST memory that the device can write: k_frame_end stores the B records there directly
+    // (180 B per sequence over PCIe) instead of a device buffer plus a copy operation per frame
+    HIPCHK(hipHostMalloc((void**)&c->h_results, sizeof(FrameResult) * SVO_RING * B, hipHostMallocMapped));
+    memset(c->h_results, 0, sizeof(FrameResult) * SVO_RING * B);
+    { void* dv = nullptr; HIPCHK(hipHostGetDevicePointer(&dv, c->h_results, 0)); d.results = (FrameResult*)dv; }
     HIPCHK(hipHostMalloc((void**)&c->h_ptrs, sizeof(uint8_t*) * SVO_RING * 2 * B));
     for (int i = 0; i < SVO_RING; i++) {
         HIPCHK(hipEventCreate(&c->ev_done[i])); HIPCHK(hipEventCreate(&c->ev_f0[i]));
@@ -259,7 +262,7 @@ static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_e
     launch_ingest(d, dp, stride, s);
     launch_pyramid(d, s);
     if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
-    launch_detect(d, 0, -1, s);
+    launch_detect(d, 0, -1, s, true);                                // k_frame_begin cleared the keys of the first pass
     launch_detect(d, 1, -1, s);
     if (with_events) HIPCHK(hipEventRecord(c->ev_lk0[slot], s));
     launch_lk_chain(d, gn, s);
@@ -268,8 +271,7 @@ static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_e
     launch_triangulate(d, s);
     if (with_events) HIPCHK(hipEventRecord(c->ev_tri[slot], s));
     launch_pnp(d, s);
-    launch_frame_end(d, slot, s);
-    HIPCHK(hipMemcpyAsync(c->h_results + (size_t)slot * B, d.results + (size_t)slot * B, sizeof(FrameResult) * B, hipMemcpyDeviceToHost, s));
+    launch_frame_end(d, slot, s);      // writes the result records straight into the pinned host ring (d.results is host memory mapped into the device)
     return SVO_OK;
 }
 
@@ -388,17 +390,21 @@ static int stage_host_images(svo_context* c, const uint8_t* const* left, const u
     const size_t rowb = (size_t)W * c->d.CN, img = rowb * H;
     if (!c->staging) HIPCHK(hipMalloc((void**)&c->staging, img * 2 * B));
     if (!c->h_staging) HIPCHK(hipHostMalloc((void**)&c->h_staging, img * 2 * B));
-    // rows are packed into pinned memory on the CPU (handles any stride), then ONE contiguous async H2D copy
-    // (a 2-D copy from pageable memory degenerates into per-row transfers: 3.5 ms per 1241x376 image)
+    // rows are packed into pinned memory on the CPU (handles any stride), then contiguous async H2D copies (a 2-D copy from
+    // pageable memory degenerates into per-row transfers: 3.5 ms per 1241x376 image).  All left images first, so that their
+    // DMA runs while the CPU packs the right ones.
     lp.resize(B); rp.resize(B);
-    for (int i = 0; i < B; i++) {
-        if (!left[i] || !right[i]) return fail_arg("null image pointer");
-        uint8_t* hl = c->h_staging + img * i; uint8_t* hr = c->h_staging + img * (B + i);
-        if ((size_t)stride == rowb) { memcpy(hl, left[i], img); memcpy(hr, right[i], img); }
-        else for (int y = 0; y < H; y++) { memcpy(hl + (size_t)y * rowb, left[i] + (size_t)y * stride, rowb); memcpy(hr + (size_t)y * rowb, right[i] + (size_t)y * stride, rowb); }
-        lp[i] = c->staging + img * i; rp[i] = c->staging + img * (B + i);
+    for (int cam = 0; cam < 2; cam++) {
+        const uint8_t* const* src = cam ? right : left;
+        for (int i = 0; i < B; i++) {
+            if (!src[i]) return fail_arg("null image pointer");
+            uint8_t* h = c->h_staging + img * (cam * B + i);
+            if ((size_t)stride == rowb) memcpy(h, src[i], img);
+            else for (int y = 0; y < H; y++) memcpy(h + (size_t)y * rowb, src[i] + (size_t)y * stride, rowb);
+            (cam ? rp : lp)[i] = c->staging + img * (cam * B + i);
+        }
+        HIPCHK(hipMemcpyAsync(c->staging + img * B * cam, c->h_staging + img * B * cam, img * B, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(hipMemcpyAsync(c->staging, c->h_staging, img * 2 * B, hipMemcpyHostToDevice, c->stream));
     return SVO_OK;
 }
 

@@ -32,6 +32,8 @@ struct SeqState {
     int fail_reason;
     int pnp_best, pnp_iters, pnp_good;
     int pnp_need;                             // hypotheses that may still be consulted by the adaptive RANSAC loop
+    int pnp_drawn;                            // RANSAC subsets drawn so far this frame
+    unsigned long long pnp_rng;               // cv::RNG state after them (the later subsets are only drawn if the loop can reach them)
     int n_inliers;
     int ok;
     double R[9], t[3], last_T[16];            // vo.h:266-268
@@ -90,7 +92,7 @@ __host__ __device__ inline size_t fastimg_index(const DevBuffers& d, int seq, in
 void launch_frame_begin(const DevBuffers& d, hipStream_t s);
 void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs /* [2][B] device array */, int stride_bytes, hipStream_t s);
 void launch_pyramid(const DevBuffers& d, hipStream_t s);
-void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s);   // pass 0: FAST_THRESHOLD, pass 1: /4 if needed; th_override >= 0 replaces it
+void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s, bool keys_cleared = false);   // pass 0: FAST_THRESHOLD, pass 1: /4 if needed; th_override >= 0 replaces it
 void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t s);      // grid_n = max features that can enter LK
 void launch_compact(const DevBuffers& d, hipStream_t s);
 void launch_triangulate(const DevBuffers& d, hipStream_t s);

@@ -16,16 +16,22 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // pyramid cache in circularMatching (vo.cpp:179-181 vs 231-232: the cache is NOT refreshed when
 // there were no points to match — the "stale pyramid" quirk).
 // ------------------------------------------------------------------------------------------------
+// Grid (blocks over the bucket grid, sequences): besides the per-frame reset (one thread per sequence) the kernel clears the
+// bucket keys for the first detection pass, which saves that pass a launch of its own (frame_id is not written here, so every
+// block can derive `active` itself).
 __global__ void k_frame_begin(DevBuffers d) {
-    int seq = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seq >= d.B) return;
+    const int seq = blockIdx.y;
     SeqState& s = d.st[seq];
+    if (s.frame_id > 0)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.NB; i += gridDim.x * blockDim.x) d.bucket_keys[(size_t)seq * d.NB + i] = 0ull;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    s.n_old = s.n_feat;
     s.active = s.frame_id > 0;
     int t1 = 0;
     for (int c = 0; c < 3; c++) if (c != s.slot_img_t0 && c != s.slot_pyr_t0) { t1 = c; break; }
     s.slot_t1 = t1;
     s.do_second = 0; s.n_lk = 0; s.n_tracks = 0; s.n_circ = 0; s.n_inliers = 0; s.ok = 0;
-    s.pnp_best = -1; s.pnp_iters = 0; s.pnp_good = 0;
+    s.pnp_best = -1; s.pnp_iters = 0; s.pnp_good = 0; s.pnp_drawn = 0;
     s.fail_reason = s.active ? 0 : 1;
     svo_frame_stats z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     s.stats = z;
@@ -52,7 +58,7 @@ __global__ void k_frame_end(DevBuffers d, int ring_slot) {
 }
 
 void launch_frame_begin(const DevBuffers& d, hipStream_t st) {
-    hipLaunchKernelGGL(k_frame_begin, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(k_frame_begin, dim3((d.NB + 255) / 256, d.B), dim3(256), 0, st, d);
 }
 void launch_frame_end(const DevBuffers& d, int ring_slot, hipStream_t st) {
     hipLaunchKernelGGL(k_frame_end, dim3((d.B + 63) / 64), dim3(64), 0, st, d, ring_slot);
@@ -579,11 +585,12 @@ static void launch_detect_general(const DevBuffers& d, int pass, int th, hipStre
     hipLaunchKernelGGL(k_gen_bucket_emit, dim3(d.B), dim3(EMIT_THREADS), 0, st, d, pass);
 }
 
-void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t st) {
+// keys_cleared: the bucket keys of this pass were already cleared (k_frame_begin does it for pass 0 of a pipeline frame)
+void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t st, bool keys_cleared) {
     int th = pass == 0 ? d.cfg.fast_threshold : d.cfg.fast_threshold / 4;            // vo.cpp:325 / :329-330
     if (th_override >= 0) th = th_override;
     if (d.cfg.features_per_bucket > 1) { launch_detect_general(d, pass, th, st); return; }
-    hipLaunchKernelGGL(k_bucket_clear, dim3((d.NB + 255) / 256, d.B), dim3(256), 0, st, d, pass);
+    if (!keys_cleared) hipLaunchKernelGGL(k_bucket_clear, dim3((d.NB + 255) / 256, d.B), dim3(256), 0, st, d, pass);
     hipLaunchKernelGGL(k_bucket_offer_old, dim3((d.CAP + 255) / 256, d.B), dim3(256), 0, st, d, pass);
     dim3 g((d.geom.W + FT_W - 1) / FT_W, (d.geom.H + FT_H - 1) / FT_H, d.B);
     hipLaunchKernelGGL(k_fast<0>, g, dim3(256), 0, st, (const uint8_t*)nullptr, 0, 0, (uint8_t*)nullptr, d, pass, th);

@@ -108,15 +108,15 @@ static __device__ void svd4_null_vector(const double (&A)[4][4], double (&X)[4])
 
 // The last block of every sequence does not triangulate: its first lane draws the RANSAC subsets (they depend on the
 // track count only), so the serial RNG walk hides under the triangulation instead of being a launch of its own.
-static __device__ void pnp_draw_subsets(const DevBuffers& d, int seq, unsigned n);
+static __device__ void pnp_draw_subsets(const DevBuffers& d, SeqState& s, int seq, int upto);
 // `lanes` tracks per wave: 64 when many sequences fill the GPU; 16 when a single stream runs alone — the Jacobi sweeps of a wave
 // last as long as its slowest lane needs, so with the GPU nearly empty fewer tracks per wave shorten the kernel (same results).
 __global__ __launch_bounds__(64) void k_triangulate(DevBuffers d, int lanes) {
     const int seq = blockIdx.y;
-    const SeqState& s = d.st[seq];
+    SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
     if (blockIdx.x == gridDim.x - 1) {
-        if (threadIdx.x == 0) pnp_draw_subsets(d, seq, (unsigned)s.n_tracks);
+        if (threadIdx.x == 0) pnp_draw_subsets(d, s, seq, 16 /* PNP_FIRST_CHUNK */);
         return;
     }
     if ((int)threadIdx.x >= lanes) return;
@@ -148,17 +148,22 @@ void launch_triangulate(const DevBuffers& d, hipStream_t st) {
 // of draws never depends on model quality.  uniform(0, n) = next() % n: the remainder is taken through the 64-bit reciprocal
 // ceil(2^64 / n) (exact for 32-bit operands: the error term x e / (n 2^64) stays below 2^-32 < 1/n), 6 instructions instead
 // of the 32-bit division sequence.
-static __device__ void pnp_draw_subsets(const DevBuffers& d, int seq, unsigned n) {
+// Draws subsets [s.pnp_drawn, upto) and leaves the generator state in s.pnp_rng: the first chunk is drawn beside the
+// triangulation, the rest only as far as the adaptive loop can still reach (k_pnp_decide) — with a static scene that is never.
+#define PNP_FIRST_CHUNK 16
+static __device__ void pnp_draw_subsets(const DevBuffers& d, SeqState& s, int seq, int upto) {
+    const unsigned n = (unsigned)s.n_tracks;
     if (n < 2) return;
+    if (upto > d.K) upto = d.K;
+    int* out = d.subsets + (size_t)seq * d.K * 5;
     if (n == 5) {                                                    // model_points == npoints: one direct solve on all five (solvepnp.cpp)
-        int* o5 = d.subsets + (size_t)seq * d.K * 5;
-        for (int i = 0; i < 5; i++) o5[i] = i;
+        for (int i = 0; i < 5; i++) out[i] = i;
+        s.pnp_drawn = d.K;
         return;
     }
-    unsigned long long state = 0xFFFFFFFFFFFFFFFFull;                // RNG rng((uint64)-1)
+    unsigned long long state = s.pnp_drawn == 0 ? 0xFFFFFFFFFFFFFFFFull : s.pnp_rng;      // RNG rng((uint64)-1)
     const unsigned long long recip = 0xFFFFFFFFFFFFFFFFull / n + 1ull;
-    int* out = d.subsets + (size_t)seq * d.K * 5;
-    for (int it = 0; it < d.K; it++) {
+    for (int it = s.pnp_drawn; it < upto; it++) {
         int idx[5];
         for (int i = 0; i < 5; i++) {
             int v; bool dup;
@@ -173,15 +178,17 @@ static __device__ void pnp_draw_subsets(const DevBuffers& d, int seq, unsigned n
         }
         for (int i = 0; i < 5; i++) out[it * 5 + i] = idx[i];
     }
+    if (upto > s.pnp_drawn) s.pnp_drawn = upto;
+    s.pnp_rng = state;
 }
 
 // stand-alone launch for callers that enter at launch_pnp without a triangulation before it (svo_camera_to_world)
 __global__ void k_pnp_subsets(DevBuffers d) {
     const int seq = blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= d.B) return;
-    const SeqState& s = d.st[seq];
+    SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
-    pnp_draw_subsets(d, seq, (unsigned)s.n_tracks);
+    pnp_draw_subsets(d, s, seq, PNP_FIRST_CHUNK);
 }
 void launch_pnp_subsets(const DevBuffers& d, hipStream_t st) {
     hipLaunchKernelGGL(k_pnp_subsets, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
@@ -821,6 +828,7 @@ __global__ void k_pnp_decide(DevBuffers d, int c0) {
         }
     }
     s.pnp_need = niters < K ? niters : K;
+    pnp_draw_subsets(d, s, seq, s.pnp_need);                         // the subsets of the hypotheses the loop can still reach
 }
 
 #define PF_THREADS 256
@@ -1291,7 +1299,6 @@ void launch_inverse_transform(const double* R, const double* t, double* T, hipSt
     hipLaunchKernelGGL(k_inverse_transform, dim3(1), dim3(64), 0, st, R, t, T);
 }
 
-#define PNP_FIRST_CHUNK 16
 void launch_pnp(const DevBuffers& d, hipStream_t st) {
     // the subsets were drawn by the last block of k_triangulate (stage entry points go through launch_triangulate too)
     const int c0 = d.K < PNP_FIRST_CHUNK ? d.K : PNP_FIRST_CHUNK;
