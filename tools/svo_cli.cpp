@@ -3,7 +3,8 @@
 //
 //   svo_cli <N_FRAMES> <folder> [--calib file.yaml] [--out result.csv] [--device d] [--gray 1] [--identity-start 1]
 //
-// Reads folder/left/frameNNNNNN.{pgm,png} (6 digits, as `run1`; 4 digits + .jpg sets are not decodable here) and
+// Reads folder/left/frameNNNNNN.{pgm,png,jpg} (6 digits, as `run1`) or frameNNNN.{jpg,png,pgm} (4 digits, as the reference's
+// other two bundled sets slam_feats/ and rand_feats/, which its current CLI cannot open; tools/jpeg_decode.hpp) and
 // folder/right/..., runs VisualOdometry::stereo_callback per pair, integrates frame_pose = frame_pose * T from the
 // 26-degree pitched initial pose (main.cpp:368-373, 396) and writes `x,y,z,gtx,gty` rows (main.cpp:346-348, 397-400),
 // reading folder/gt.csv with the reference's column quirk (main.cpp:336-344, 385-392).
@@ -27,6 +28,7 @@
 #include <string>
 #include <vector>
 #include "svo/visual_odometry.hpp"
+#include "jpeg_decode.hpp"
 using namespace visual_odometry;
 
 struct Gray { int w = 0, h = 0; std::vector<uint8_t> px, bgr; bool ok() const { return w > 0; } };   // px: gray, bgr: interleaved B,G,R
@@ -101,10 +103,29 @@ static Gray read_png(const std::vector<uint8_t>& d) {
     return g;
 }
 
-static Gray read_image(const std::string& base) {
+static Gray read_jpeg(const std::vector<uint8_t>& d) {
+    Gray g;
+    svo_jpeg::Image im = svo_jpeg::decode(d.data(), d.size());
+    if (!im.ok) return g;
+    g.w = im.w; g.h = im.h; g.px.resize((size_t)im.w * im.h); g.bgr.resize((size_t)im.w * im.h * 3);
+    for (size_t i = 0; i < (size_t)im.w * im.h; i++) {
+        const int R = im.px[i * im.channels], G = im.channels == 3 ? im.px[i * 3 + 1] : R, B = im.channels == 3 ? im.px[i * 3 + 2] : R;
+        g.px[i] = im.channels == 3 ? (uint8_t)((B * 1868 + G * 9617 + R * 4899 + 8192) >> 14) : (uint8_t)R;    // BGR2GRAY
+        g.bgr[3 * i] = (uint8_t)B; g.bgr[3 * i + 1] = (uint8_t)G; g.bgr[3 * i + 2] = (uint8_t)R;                // cv::imread: BGR
+    }
+    return g;
+}
+
+// folder/side/frame%06d.* (run1's naming, main.cpp:21-36) or frame%04d.* (slam_feats / rand_feats)
+static Gray read_image(const std::string& dir, int index) {
     std::vector<uint8_t> d;
-    if (read_file(base + ".pgm", d)) return read_pgm(d);
-    if (read_file(base + ".png", d)) return read_png(d);
+    for (const char* fmt : {"/frame%06d", "/frame%04d"}) {
+        char name[64]; std::snprintf(name, sizeof(name), fmt, index);
+        const std::string base = dir + name;
+        if (read_file(base + ".pgm", d)) return read_pgm(d);
+        if (read_file(base + ".png", d)) return read_png(d);
+        if (read_file(base + ".jpg", d)) return read_jpeg(d);
+    }
     return Gray();
 }
 
@@ -167,8 +188,7 @@ int main(int argc, char** argv) {
         if (identity_start) { const double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; memcpy(pose, I, sizeof(I)); }
         int done = 0;
         for (int i = 0; i < N_FRAMES; i++) {
-            char name[64]; std::snprintf(name, sizeof(name), "/frame%06d", i);
-            Gray l = read_image(folder + "/left" + name), r = read_image(folder + "/right" + name);
+            Gray l = read_image(folder + "/left", i), r = read_image(folder + "/right", i);
             if (!l.ok() || !r.ok() || l.w != r.w || l.h != r.h) break;                                   // stop at the first missing pair
             double gtx = 0, gty = 0;
             if (has_gt) {
