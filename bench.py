@@ -69,8 +69,8 @@ def main():
     ap.add_argument("--depth", type=int, default=4, help="frames kept in flight per context (<= 8)")
     ap.add_argument("--contexts", type=int, default=2, help="sequence groups per GPU, each on its own HIP stream (their kernels overlap)")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic sequences rendered per rank (own seed each)")
-    ap.add_argument("--movers", type=float, default=0.3, help="fraction of the pixels covered by an independently moving foreground layer "
-                    "(RANSAC-PnP outliers; 0 = static scene, the best case for PnP)")
+    ap.add_argument("--movers", type=float, default=None, help="fraction of the pixels covered by an independently moving foreground layer "
+                    "(RANSAC-PnP outliers; 0 = static scene, the best case for PnP).  Default: 0.3 for cfg2 (the metric's workload), 0 for the others")
     ap.add_argument("--frames", type=int, default=10, help="frames rendered per pool sequence (ping-pong replay)")
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg5"],
@@ -137,6 +137,8 @@ def main():
                  "BASELINE configs[4]: ZED calibration, 1920x1080, ~8000 features, LK 21x21 win, maxLevel 3, 100 RANSAC-PnP iterations"),
     }
     cal, scene, cfg_over, workload_name = WL[args.workload]
+    if args.movers is None:
+        args.movers = 0.3 if args.workload == "cfg2" else 0.0
     W, H = cal["width"], cal["height"]
     over = dict(win_w=win, win_h=win, max_translation_norm=2.0, **cfg_over)
     B, F = args.seqs, args.frames

@@ -29,7 +29,43 @@ def pmc_mean(d, counter, kernel, drop_small=True):
     return sum(vals) / max(len(vals), 1), len(vals)
 
 
+def sq_summary(tag, sq_dir, bench_json, extra_dirs=(), gui_dir=None, kernel="k_lk_chain"):
+    """profiles/<tag>_lk_chain_sq.json from a `--pmc SQ_*` pass (<= 8 counters per pass: more "exceeds the capabilities of the
+    hardware"), optional further passes (other counters) and an optional GRBM_GUI_ACTIVE pass for the clock the chip held;
+    features per launch come from the bench line of the same configuration (mean_features_into_lk x sequences per launch)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    counters = {}
+    for d in (sq_dir,) + tuple(extra_dirs):
+        names = {r["Counter_Name"] for r in csv.DictReader(open(find(d, "*counter_collection.csv"))) if kernel in r["Kernel_Name"]}
+        for n in sorted(names):
+            counters[n], launches = pmc_mean(d, n, kernel)
+    j = json.loads(open(bench_json).read().strip().splitlines()[-1])
+    seqs = j["config"]["sequences_per_gpu"] // j["config"]["contexts_per_gpu"]
+    feats = j["config"]["mean_features_into_lk"] * seqs
+    out = {"kernel": j["roofline"]["kernel"], "sequences_per_launch": seqs, "features_per_launch": feats, "launches_averaged": launches,
+           "counters_per_launch": counters, "valu_instructions_per_feature": counters["SQ_INSTS_VALU"] / feats,
+           "newton_steps_per_feature": j["roofline"]["valu_flop"]["newton_steps_per_feature"],
+           "level_visits_per_feature": j["roofline"]["valu_flop"]["level_visits_per_feature"],
+           "kernel_avg_ms_unprofiled": j["roofline"]["kernel_avg_ms"],
+           "valu_busy_frac": counters["SQ_ACTIVE_INST_VALU"] / (counters["SQ_WAVE_CYCLES"] / 4.0) if "SQ_ACTIVE_INST_VALU" in counters else None,
+           "note": "rocprofv3 --pmc; SQ_WAVE_CYCLES / WAIT / ACTIVE are in quad-cycles summed over waves; valu_busy_frac = SQ_ACTIVE_INST_VALU / "
+                   "(SQ_WAVE_CYCLES / 4 wave slots per SIMD): the share of time a SIMD's VALU is issuing for this kernel"}
+    if gui_dir:
+        g, _ = pmc_mean(gui_dir, "GRBM_GUI_ACTIVE", kernel)
+        kt = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(find(gui_dir, "*kernel_trace.csv"))) if kernel in r["Kernel_Name"]]
+        kt = [t for t in kt if t > 0.05 * max(kt)]
+        out["GRBM_GUI_ACTIVE_per_launch"] = g
+        out["effective_clock_GHz"] = g / 8.0 / (sum(kt) / len(kt))      # the counter sums the 8 XCDs; duration in ns
+    json.dump(out, open(os.path.join(here, tag + "_lk_chain_sq.json"), "w"), indent=1)
+    print(out)
+
+
 def main():
+    if "--sq" in sys.argv:                  # summarize.py <tag> --sq <sq_dir> --bench <bench.json> [--extra dir ...] [--gui dir]
+        a = sys.argv
+        extra = [a[i + 1] for i, x in enumerate(a) if x == "--extra"]
+        sq_summary(a[1], a[a.index("--sq") + 1], a[a.index("--bench") + 1], tuple(extra), a[a.index("--gui") + 1] if "--gui" in a else None)
+        return
     a = [x for i, x in enumerate(sys.argv[1:], 1) if not x.startswith("--") and sys.argv[i - 1] not in ("--seqs", "--kernel")]
     kernel = "k_lk_chain"
     if "--kernel" in sys.argv:

@@ -145,7 +145,7 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
         ALLOC(d.slot_xy, B * SL); ALLOC(d.slot_age, B * SL); ALLOC(d.slot_str, B * SL); ALLOC(d.slot_n, B * (size_t)d.NB);
     }
     ALLOC(d.pl0, B * CAP); ALLOC(d.pl1, B * CAP); ALLOC(d.pr1, B * CAP); ALLOC(d.pr0, B * CAP); ALLOC(d.plc, B * CAP);
-    ALLOC(d.okmask, B * CAP);
+    ALLOC(d.okmask, B * CAP); ALLOC(d.lk_work, B * CAP);
     ALLOC(d.tl0, B * CAP); ALLOC(d.tr0, B * CAP); ALLOC(d.tl1, B * CAP); ALLOC(d.tr1, B * CAP);
     ALLOC(d.world, B * CAP * 3); ALLOC(d.inlier, B * CAP); ALLOC(d.inl_idx, B * CAP);
     ALLOC(d.subsets, B * (size_t)d.K * 5); ALLOC(d.hyp, B * (size_t)d.K * 12); ALLOC(d.hyp_good, B * (size_t)d.K);

@@ -68,6 +68,7 @@ struct DevBuffers {
     int* slot_n;                               // [B][NB]
     float2 *pl0, *pl1, *pr1, *pr0, *plc;       // [B][CAP] raw LK outputs
     uint8_t* okmask;                           // [B][CAP] bit0 circular ok, bit1 in-bounds
+    unsigned* lk_work;                         // [B][CAP] per feature: Newton steps << 8 | level visits of its four passes (summed by k_compact)
     float2 *tl0, *tr0, *tl1, *tr1;             // [B][CAP] compacted tracks
     float* world;                              // [B][CAP][3]
     uint8_t* inlier;                           // [B][CAP]

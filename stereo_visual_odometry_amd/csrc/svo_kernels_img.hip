@@ -664,7 +664,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_compact(DevBuffers d) {
     const int chunk = (n + SCAN_THREADS - 1) / SCAN_THREADS;
     const int i0 = threadIdx.x * chunk < n ? threadIdx.x * chunk : n, i1 = (i0 + chunk < n) ? i0 + chunk : n;
     int cnt = 0, cntc = 0;
-    for (int i = i0; i < i1; i++) { uint8_t m = d.okmask[o + i]; cnt += (m == 3); cntc += (m & 1); }
+    unsigned visits = 0, steps = 0;                                  // svo_frame_stats.lk_level_visits / lk_newton_steps
+    for (int i = i0; i < i1; i++) {
+        uint8_t m = d.okmask[o + i]; cnt += (m == 3); cntc += (m & 1);
+        const unsigned wk = d.lk_work[o + i]; visits += wk & 0xFFu; steps += wk >> 8;
+    }
+    for (int k = 32; k > 0; k >>= 1) { visits += __shfl_xor(visits, k); steps += __shfl_xor(steps, k); }
+    if ((threadIdx.x & 63) == 0 && (visits | steps)) { atomicAdd(&s.stats.lk_level_visits, (int)visits); atomicAdd(&s.stats.lk_newton_steps, (int)steps); }
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int incl = cnt, inclc = cntc;
     for (int k = 1; k < 64; k <<= 1) { int t = __shfl_up(incl, k), tc = __shfl_up(inclc, k); if (lane >= k) { incl += t; inclc += tc; } }

@@ -661,8 +661,7 @@ static __device__ void epnp_branch(double* ar, int branch, double fu, double fv,
 
 // Hypotheses [h0, h1).  The first chunk (h0 == 0) is always solved; later chunks only up to s.pnp_need, the bound the
 // adaptive loop had reached after the first chunk (the bound only ever shrinks, so nothing beyond it can be consulted).
-__global__ __launch_bounds__(EP_G * EP_HPB) void k_pnp_epnp(DevBuffers d, int h0, int h1) {
-    __shared__ double arena[EP_HPB * EP_STRIDE];
+static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0, int h1, double* arena) {
     const int seq = blockIdx.y;
     const SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
@@ -720,6 +719,19 @@ __global__ __launch_bounds__(EP_G * EP_HPB) void k_pnp_epnp(DevBuffers d, int h0
         double* out = d.hyp + ((size_t)seq * d.K + h) * 12;
         for (int i = 0; i < 12; i++) out[i] = w[1 + i];
     }
+}
+
+// Two builds of the same body.  The register-resident linear algebra makes the kernel want ~316 VGPRs: that is the fastest
+// form when a single stream runs alone (latency), but with many sequences its waves sit beside the other context's LK waves,
+// and every 104 registers they hold is one LK wave less per SIMD.  The lean build is limited to the architected 128 VGPRs
+// (+ AGPR spill space, 257 in all): measured +2.4 % whole-job rate at 256 sequences, same results.
+__global__ __launch_bounds__(EP_G * EP_HPB) void k_pnp_epnp(DevBuffers d, int h0, int h1) {
+    __shared__ double arena[EP_HPB * EP_STRIDE];
+    pnp_epnp_body(d, h0, h1, arena);
+}
+__global__ __launch_bounds__(EP_G * EP_HPB) __attribute__((amdgpu_num_vgpr(128))) void k_pnp_epnp_lean(DevBuffers d, int h0, int h1) {
+    __shared__ double arena[EP_HPB * EP_STRIDE];
+    pnp_epnp_body(d, h0, h1, arena);
 }
 
 // ------------------------------------------------------------------------------------------------ hypothesis scoring
@@ -1302,11 +1314,14 @@ void launch_inverse_transform(const double* R, const double* t, double* T, hipSt
 void launch_pnp(const DevBuffers& d, hipStream_t st) {
     // the subsets were drawn by the last block of k_triangulate (stage entry points go through launch_triangulate too)
     const int c0 = d.K < PNP_FIRST_CHUNK ? d.K : PNP_FIRST_CHUNK;
-    hipLaunchKernelGGL(k_pnp_epnp, dim3((c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, 0, c0);
+    const bool lean = d.B > 8;                                       // see k_pnp_epnp_lean
+    if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, 0, c0);
+    else hipLaunchKernelGGL(k_pnp_epnp, dim3((c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, 0, c0);
     hipLaunchKernelGGL(k_pnp_score, dim3(c0, d.B), dim3(256), 0, st, d, 0, c0);
     if (d.K > c0) {
         hipLaunchKernelGGL(k_pnp_decide, dim3((d.B + 63) / 64), dim3(64), 0, st, d, c0);
-        hipLaunchKernelGGL(k_pnp_epnp, dim3((d.K - c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, c0, d.K);
+        if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((d.K - c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, c0, d.K);
+        else hipLaunchKernelGGL(k_pnp_epnp, dim3((d.K - c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, c0, d.K);
         hipLaunchKernelGGL(k_pnp_score, dim3(d.K - c0, d.B), dim3(256), 0, st, d, c0, d.K);
     }
     hipLaunchKernelGGL(k_pnp_final, dim3(d.B), dim3(PF_THREADS), 0, st, d);
