@@ -62,3 +62,17 @@ def test_bench_runs_its_exchange_through_rccl():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["pose_ok_fraction"] > 0.9
+
+
+def test_bench_two_ranks_end_to_end_on_one_gpu_gloo():
+    """The N > 1 path of bench.py on hardware, as far as a one-GPU box allows: `python bench.py --gpus 2` starts two ranks itself
+    (torch.distributed.run child); both use GPU 0 (--same-device) and exchange over gloo, because RCCL refuses two ranks on one
+    device.  Sharded sequences, barrier, max-over-ranks timing, the pose-stream gather to rank 0 and the reductions all run; the
+    line says n_gpus 2 and counts both ranks' sequences."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "3",
+                        "--warmup", "1", "--seqs", "8", "--contexts", "1", "--pool", "2", "--cpu-frames", "0"],
+                       env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["sequences_per_gpu"] == 8 and line["config"]["pose_ok_fraction"] > 0.9
+    assert abs(line["value"] - 2 * 8 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]     # whole-job rate over both ranks
