@@ -89,6 +89,11 @@ __host__ __device__ inline size_t fastimg_index(const DevBuffers& d, int seq, in
     return (size_t)(seq * 3 + slot) * (size_t)d.geom.W * (size_t)d.geom.H;
 }
 
+// Hypotheses of the first RANSAC chunk (always solved).  16 when many sequences share the GPU; 32 for a lone stream: the GPU is
+// empty then, a wider chunk costs no time, and the adaptive loop (11-27 iterations with 30 % outliers) rarely needs a second
+// EPnP launch — which would be another 145 us on the critical path.
+__host__ __device__ inline int pnp_first_chunk(const DevBuffers& d) { const int c = d.B <= 8 ? 32 : 16; return d.K < c ? d.K : c; }
+
 // ---- launchers (each enqueues on `s`; none synchronises) ----
 void launch_frame_begin(const DevBuffers& d, hipStream_t s);
 void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs /* [2][B] device array */, int stride_bytes, hipStream_t s);

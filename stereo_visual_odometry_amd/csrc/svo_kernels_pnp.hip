@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void k_triangulate(DevBuffers d, int lanes) {
     SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
     if (blockIdx.x == gridDim.x - 1) {
-        if (threadIdx.x == 0) pnp_draw_subsets(d, s, seq, 16 /* PNP_FIRST_CHUNK */);
+        if (threadIdx.x == 0) pnp_draw_subsets(d, s, seq, pnp_first_chunk(d));
         return;
     }
     if ((int)threadIdx.x >= lanes) return;
@@ -150,7 +150,6 @@ void launch_triangulate(const DevBuffers& d, hipStream_t st) {
 // of the 32-bit division sequence.
 // Draws subsets [s.pnp_drawn, upto) and leaves the generator state in s.pnp_rng: the first chunk is drawn beside the
 // triangulation, the rest only as far as the adaptive loop can still reach (k_pnp_decide) — with a static scene that is never.
-#define PNP_FIRST_CHUNK 16
 static __device__ void pnp_draw_subsets(const DevBuffers& d, SeqState& s, int seq, int upto) {
     const unsigned n = (unsigned)s.n_tracks;
     if (n < 2) return;
@@ -188,7 +187,7 @@ __global__ void k_pnp_subsets(DevBuffers d) {
     if (seq >= d.B) return;
     SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
-    pnp_draw_subsets(d, s, seq, PNP_FIRST_CHUNK);
+    pnp_draw_subsets(d, s, seq, pnp_first_chunk(d));
 }
 void launch_pnp_subsets(const DevBuffers& d, hipStream_t st) {
     hipLaunchKernelGGL(k_pnp_subsets, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
@@ -1313,7 +1312,7 @@ void launch_inverse_transform(const double* R, const double* t, double* T, hipSt
 
 void launch_pnp(const DevBuffers& d, hipStream_t st) {
     // the subsets were drawn by the last block of k_triangulate (stage entry points go through launch_triangulate too)
-    const int c0 = d.K < PNP_FIRST_CHUNK ? d.K : PNP_FIRST_CHUNK;
+    const int c0 = pnp_first_chunk(d);
     const bool lean = d.B > 8;                                       // see k_pnp_epnp_lean
     if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, 0, c0);
     else hipLaunchKernelGGL(k_pnp_epnp, dim3((c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, 0, c0);
