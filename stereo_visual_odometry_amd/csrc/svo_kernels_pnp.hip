@@ -256,86 +256,9 @@ static __device__ bool rotate_pair12(double* At, double* Wv, double* Vt, int i, 
     return true;
 }
 
-// One-sided Jacobi SVD with RUN-TIME sizes (the same sweep order and arithmetic as jacobi_svd<M, N> in svo_linalg.hpp): the
-// three beta approximations of EPnP solve 6x4, 6x3 and 6x5 systems on three lanes of one wave — as three template instances
-// they were three code paths the wave executed one after the other; with the size in a register the lanes run ONE path together
-// and only the trip counts differ.  At: n rows of length m; Vt: n x n; Wv: n.
-static __device__ void jacobi_svd_rt(double* At, int m, int n, double* Wv, double* Vt, int n1) {
-    const double eps = SVO_DBL_EPS * 10, minval = SVO_DBL_MIN;
-    const int max_iter = m > 30 ? m : 30;
-#pragma unroll 1
-    for (int i = 0; i < n; i++) {
-        double sd = 0;
-        for (int k = 0; k < m; k++) { double t = At[i * m + k]; sd += t * t; }
-        Wv[i] = sd;
-        for (int k = 0; k < n; k++) Vt[i * n + k] = 0;
-        Vt[i * n + i] = 1;
-    }
-#pragma unroll 1
-    for (int iter = 0; iter < max_iter; iter++) {
-        bool changed = false;
-#pragma unroll 1
-        for (int i = 0; i < n - 1; i++)
-#pragma unroll 1
-            for (int j = i + 1; j < n; j++) {
-                double* Ai = At + i * m; double* Aj = At + j * m;
-                double a = Wv[i], p = 0, b = Wv[j], c, s;
-                for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
-                if (fabs(p) <= eps * sqrt(a * b)) continue;
-                p *= 2;
-                double beta = a - b, gamma = sqrt(p * p + beta * beta);
-                if (beta < 0) {
-                    double delta = (gamma - beta) * 0.5;
-                    s = sqrt(delta / gamma);
-                    c = p / (gamma * s * 2);
-                } else {
-                    c = sqrt((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
-                }
-                a = b = 0;
-                for (int k = 0; k < m; k++) {
-                    double t0 = c * Ai[k] + s * Aj[k];
-                    double t1 = -s * Ai[k] + c * Aj[k];
-                    Ai[k] = t0; Aj[k] = t1;
-                    a += t0 * t0; b += t1 * t1;
-                }
-                Wv[i] = a; Wv[j] = b;
-                changed = true;
-                double* Vi = Vt + i * n; double* Vj = Vt + j * n;
-                for (int k = 0; k < n; k++) {
-                    double t0 = c * Vi[k] + s * Vj[k];
-                    double t1 = -s * Vi[k] + c * Vj[k];
-                    Vi[k] = t0; Vj[k] = t1;
-                }
-            }
-        if (!changed) break;
-    }
-#pragma unroll 1
-    for (int i = 0; i < n; i++) {
-        double sd = 0;
-        for (int k = 0; k < m; k++) { double t = At[i * m + k]; sd += t * t; }
-        Wv[i] = sqrt(sd);
-    }
-#pragma unroll 1
-    for (int i = 0; i < n - 1; i++) {
-        int j = i;
-        for (int k = i + 1; k < n; k++) if (Wv[j] < Wv[k]) j = k;
-        if (i != j) {
-            double t = Wv[i]; Wv[i] = Wv[j]; Wv[j] = t;
-            for (int k = 0; k < m; k++) { t = At[i * m + k]; At[i * m + k] = At[j * m + k]; At[j * m + k] = t; }
-            for (int k = 0; k < n; k++) { t = Vt[i * n + k]; Vt[i * n + k] = Vt[j * n + k]; Vt[j * n + k] = t; }
-        }
-    }
-#pragma unroll 1
-    for (int i = 0; i < n1; i++) {
-        double sd = i < n ? Wv[i] : 0;
-        double s = sd > minval ? 1 / sd : 0.;
-        for (int k = 0; k < m; k++) At[i * m + k] *= s;
-    }
-}
-
-// x = pinv(A) b for A: 6 x n (n = 3, 4, 5) on REGISTERS: the system is zero-padded to five columns so that the three beta
-// approximations run one instruction stream.  A zero row of At never rotates (p = 0 <= eps sqrt(a b) = 0), keeps its singular
+// x = pinv(A) b for A: 6 x n (n = 3, 4, 5) on REGISTERS.  The three beta approximations of EPnP solve 6x4, 6x3 and 6x5 systems on
+// three lanes of one wave — as three template instances they were three code paths the wave executed one after the other; here
+// the system is zero-padded to five columns so that they run one instruction stream.  A zero row of At never rotates (p = 0 <= eps sqrt(a b) = 0), keeps its singular
 // value 0 (<= the threshold: dropped) and leaves the identity columns of Vt alone, so the n x n part is computed exactly as the
 // unpadded routine computes it, bit for bit.
 static __device__ void svd_solve6_reg(const double* A, int n, const double* b, double* x) {
@@ -364,25 +287,6 @@ static __device__ void svd_solve6_reg(const double* A, int n, const double* b, d
     }
 #pragma unroll
     for (int k = 0; k < N; k++) if (k < n) x[k] = xx[k];
-}
-
-// x = pinv(A) b (A: 6 x n row-major, n <= 5) through that SVD; workspace ws needs n*6 + n*n + n <= 60 doubles
-static __device__ void svd_solve6_rt(const double* A, int n, const double* b, double* x, double* ws) {
-    const int M = 6;
-    double* Ut = ws; double* Vt = ws + n * M; double* Wv = Vt + n * n;
-    for (int i = 0; i < n; i++) for (int j = 0; j < M; j++) Ut[i * M + j] = A[j * n + i];
-    jacobi_svd_rt(Ut, M, n, Wv, Vt, n);
-    double thr = 0;
-    for (int i = 0; i < n; i++) thr += Wv[i];
-    thr *= SVO_DBL_EPS * 2;
-    for (int k = 0; k < n; k++) x[k] = 0;
-    for (int i = 0; i < n; i++) {
-        if (Wv[i] <= thr) continue;
-        double s = 0;
-        for (int k = 0; k < M; k++) s += Ut[i * M + k] * b[k];
-        s /= Wv[i];
-        for (int k = 0; k < n; k++) x[k] += s * Vt[i * n + k];
-    }
 }
 
 // Householder QR least squares for the 6 x 4 Gauss-Newton step, on registers with compile-time indices (the arithmetic and its
