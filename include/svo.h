@@ -123,7 +123,8 @@ int svo_submit_batch(svo_context* ctx, const uint8_t* const* left_dev, const uin
 int svo_collect(svo_context* ctx, double* T_out, int* ok_out, svo_frame_stats* stats);
 
 /* Introspection (parity tests): currentVOFeatures (vo.h:245) of one sequence, and the last frame's
- * compacted tracks.  Arrays may be NULL.  Returns the count or a negative status. */
+ * compacted tracks.  Arrays may be NULL.  Returns the count or a negative status.  inlier[] is the is_ok vector of vo.cpp:115-119:
+ * all zero when the frame failed before it was built (RANSAC failure or fewer inliers than features_threshold, vo.cpp:106-113). */
 int svo_get_features(svo_context* ctx, int seq, int cap, float* xy, int* ages, int* strengths);
 int svo_get_last_tracks(svo_context* ctx, int seq, int cap, float* pl0, float* pr0, float* pl1, float* pr1,
                         float* world, uint8_t* inlier);

@@ -952,7 +952,12 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
         s.t[0] = sh.param[3]; s.t[1] = sh.param[4]; s.t[2] = sh.param[5];
         s.n_inliers = n_inl;
     }
-    if (n_inl < d.cfg.features_threshold) { if (threadIdx.x == 0) s.fail_reason = 3; return; }   // vo.cpp:106-113
+    if (n_inl < d.cfg.features_threshold) {                                                      // vo.cpp:106-113
+        // the reference builds its is_ok vector only past this gate (vo.cpp:115): on this path no inlier flags exist
+        for (int i = threadIdx.x; i < n; i += PF_THREADS) d.inlier[o + i] = 0;
+        if (threadIdx.x == 0) s.fail_reason = 3;
+        return;
+    }
     {
         int pos = sh.wave_tot[wv] + incl - cnt;
         const int* fage = d.feat_age[fb] + o; const int* fstr = d.feat_str[fb] + o;

@@ -3,6 +3,8 @@
 Bar: bit-exact for integer / byte / index work and for every validity mask; float point positions are
 compared bit-for-bit too (the LK arithmetic is exact-integer + IEEE f32); poses within POSE_TOL.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -669,7 +671,10 @@ class _Frames:
         self.cal, self.left, self.right = seq.cal, left, right
 
 
-@pytest.mark.parametrize("case", range(16))
+FUZZ_CASES = int(os.environ.get("SVO_FUZZ_CASES", "16"))          # the suite runs 16; SVO_FUZZ_CASES=400 for a one-off sweep
+
+
+@pytest.mark.parametrize("case", range(FUZZ_CASES))
 def test_fuzz_scenes_and_configs(api, case):
     """Seeded random scenes x image degradations x configurations: high contrast (the wide LK reductions), low contrast
     (minimum-eigenvalue rejections), noise, black bars (windows over flat areas and borders), every window / level count,
@@ -693,7 +698,12 @@ def test_fuzz_scenes_and_configs(api, case):
         return out
 
     fr = _Frames(seq, [degrade(seq.left[k], k, 0) for k in range(4)], [degrade(seq.right[k], k, 1) for k in range(4)])
-    win = int(rng.choice([7, 10, 15, 21, 31]))
+    win = int(rng.choice([7, 10, 15, 21, 31])) if case < 16 else int(rng.integers(5, 32))     # later cases: any window 5..31
+    movers = 0.0 if case < 16 else float(rng.choice([0.0, 0.2, 0.4]))
+    if movers:
+        seq = syn.StereoSequence(cal=cal, n_frames=4, seed=500 + case, step=float(rng.uniform(0.1, 0.7)), movers=movers, mover_step=(0.3, 0.1),
+                                 yaw_amp_deg=float(rng.uniform(0.0, 1.2)), cell_px=float(rng.uniform(9.0, 22.0)))
+        fr = _Frames(seq, [degrade(seq.left[k], k, 0) for k in range(4)], [degrade(seq.right[k], k, 1) for k in range(4)])
     over = dict(win_w=win, win_h=win, max_level=int(rng.integers(1, 5)), fast_threshold=int(rng.choice([8, 20, 35])),
                 ransac_iterations=int(rng.choice([20, 100, 250])), ransac_reprojection_error=float(rng.choice([1.0, 8.0])),
                 optical_flow_min_eig_threshold=float(rng.choice([1e-4, 1e-3, 3e-2])),
