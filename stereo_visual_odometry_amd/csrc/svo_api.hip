@@ -129,6 +129,10 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     c->lk_grid = (cfg.max_features > 0 && cfg.max_features < d.CAP) ? cfg.max_features : d.CAP;
     make_geometry(d.geom, width, height, cfg.win_w, cfg.max_level);
     d.lk_mineig_cut = lk_mineig_cut(cfg.win_w, cfg.optical_flow_min_eig_threshold);
+    {
+        double pc = (double)cfg.ransac_confidence; pc = pc > 0. ? pc : 0.; pc = pc < 1. ? pc : 1.;
+        d.ransac_log_num = log(1. - pc > 2.2250738585072014e-308 ? 1. - pc : 2.2250738585072014e-308);
+    }
     const size_t B = n_seq, CAP = d.CAP;
     int rc;
 #define ALLOC(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != SVO_OK) return rc;

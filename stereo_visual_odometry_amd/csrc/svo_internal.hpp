@@ -76,6 +76,7 @@ struct DevBuffers {
     double* hyp;                               // [B][K][12]  (R row-major, t)
     int* hyp_good;                             // [B][K]
     int* inl_idx;                              // [B][CAP]
+    double ransac_log_num;                     // log(max(1 - confidence, DBL_MIN)): the numerator of RANSACUpdateNumIters, computed by the host
     const double* lm_lambda;                   // [33] 10^k, k = -16..16 (the damping factors CvLevMarq can reach), computed on the host
     FrameResult* results;                      // [SVO_RING][B]
     const uint8_t** img_ptrs;                  // [SVO_RING][2][B] device array of source image pointers

@@ -17,7 +17,7 @@
 #include "svo_linalg.hpp"
 
 static __device__ __forceinline__ bool seq_live(const SeqState& s) { return s.active && s.fail_reason == 0; }
-static __device__ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
+static __device__ int ransac_update_num_iters(double log_num, double ep, int max_iters);
 
 // ------------------------------------------------------------------------------------------------ triangulation
 // ---- the 4 x 4 SVD of the triangulation, register-resident.  jacobi_svd<4, 4> walks its row pairs with run-time indices; on
@@ -680,15 +680,16 @@ __global__ __launch_bounds__(256) void k_pnp_score(DevBuffers d, int h0, int h1)
 }
 
 // ------------------------------------------------------------------------------------------------ replay + refine + pose
-static __device__ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters) {
-    p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
+// RANSACUpdateNumIters(confidence, ep, modelPoints = 5, maxIters) of ptsetreg.cpp.  log(1 - confidence) is constant per context
+// and comes from the host; (1 - ep)^5 is three multiplications instead of a generic f64 pow (a few hundred instructions on the one
+// thread everything waits for) — within 2 ulp of it, and the result only enters through rint(num / denom).
+static __device__ int ransac_update_num_iters(double log_num, double ep, int max_iters) {
     ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
-    double num = 1. - p > SVO_DBL_MIN ? 1. - p : SVO_DBL_MIN;
-    double denom = 1. - pow(1. - ep, (double)model_points);
+    const double x = 1. - ep, x2 = x * x;
+    double denom = 1. - x2 * x2 * x;
     if (denom < SVO_DBL_MIN) return 0;
-    num = log(num);
     denom = log(denom);
-    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+    return denom >= 0 || -log_num >= max_iters * (-denom) ? max_iters : (int)rint(log_num / denom);
 }
 
 // Cholesky solve of a 6x6 SPD system (the damped normal equations of the LM step)
@@ -739,7 +740,7 @@ __global__ void k_pnp_decide(DevBuffers d, int c0) {
         int g = good[it];
         if (g > (max_good > 4 ? max_good : 4)) {
             max_good = g;
-            niters = ransac_update_num_iters((double)d.cfg.ransac_confidence, (double)(n - g) / n, 5, niters);
+            niters = ransac_update_num_iters(d.ransac_log_num, (double)(n - g) / n, niters);
         }
     }
     s.pnp_need = niters < K ? niters : K;
@@ -863,7 +864,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
             iters_run = it + 1;
             if (g > (max_good > 4 ? max_good : 4)) {
                 max_good = g; best = it;
-                niters = ransac_update_num_iters((double)d.cfg.ransac_confidence, (double)(n - g) / n, 5, niters);
+                niters = ransac_update_num_iters(d.ransac_log_num, (double)(n - g) / n, niters);
             }
         }
         s.pnp_best = best; s.pnp_iters = iters_run; s.pnp_good = max_good;
