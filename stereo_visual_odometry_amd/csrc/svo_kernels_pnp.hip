@@ -694,7 +694,10 @@ static __device__ int ransac_update_num_iters(double log_num, double ep, int max
 
 // Cholesky solve of a 6x6 SPD system (the damped normal equations of the LM step)
 static __device__ void chol_solve6(const double* A, const double* b, double* x) {
-    double Lm[6][6];                                                  // every index below is a compile-time constant: registers
+    // every index below is a compile-time constant: registers.  One reciprocal per pivot (6 divisions instead of 27: each f64
+    // division is ~25 dependent instructions on the thread the whole block waits for); the LM refine is compared with the oracle
+    // to the pose tolerance, not bit for bit (the oracle solves the same system through an SVD, as cv::solve(DECOMP_SVD) does).
+    double Lm[6][6], inv[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
 #pragma unroll
@@ -702,8 +705,8 @@ static __device__ void chol_solve6(const double* A, const double* b, double* x) 
             double s = A[6 * i + j];
 #pragma unroll
             for (int k = 0; k < j; k++) s -= Lm[i][k] * Lm[j][k];
-            if (i == j) Lm[i][i] = sqrt(s > 1e-300 ? s : 1e-300);
-            else Lm[i][j] = s / Lm[j][j];
+            if (i == j) { Lm[i][i] = sqrt(s > 1e-300 ? s : 1e-300); inv[i] = 1.0 / Lm[i][i]; }
+            else Lm[i][j] = s * inv[j];
         }
     }
     double y[6], xx[6];
@@ -712,14 +715,14 @@ static __device__ void chol_solve6(const double* A, const double* b, double* x) 
         double s = b[i];
 #pragma unroll
         for (int k = 0; k < i; k++) s -= Lm[i][k] * y[k];
-        y[i] = s / Lm[i][i];
+        y[i] = s * inv[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
         double s = y[i];
 #pragma unroll
         for (int k = i + 1; k < 6; k++) s -= Lm[k][i] * xx[k];
-        xx[i] = s / Lm[i][i];
+        xx[i] = s * inv[i];
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) x[i] = xx[i];
