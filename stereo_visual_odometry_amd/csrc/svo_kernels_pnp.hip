@@ -750,7 +750,8 @@ __global__ void k_pnp_decide(DevBuffers d, int c0) {
     pnp_draw_subsets(d, s, seq, s.pnp_need);                         // the subsets of the hypotheses the loop can still reach
 }
 
-#define PF_THREADS 256
+#define PF_THREADS 512
+#define PF_WAVES (PF_THREADS / 64)
 // the value of lane (dpp-permuted) of a double: DPP works on 32-bit registers, so move the halves separately
 static __device__ __forceinline__ double dpp_f64(double v, const int ctrl_unused);
 template <int CTRL> static __device__ __forceinline__ double dpp_f64_t(double v) {
@@ -769,11 +770,11 @@ static __device__ __forceinline__ double dpp_f64(double v, const int ctrl) {
 }
 struct LmShared {
     double param[6], prev[6], R[9], dRdr[27], JtJ[36], JtErr[6];
-    double red[4][28];
+    double red[PF_WAVES][28];
     double prevErrNorm;
     int lambdaLg10, iters, state, mode;
     const double* lambda_tab;
-    int wave_tot[4]; int total;
+    int wave_tot[PF_WAVES]; int total;
 };
 
 // one evaluation of residuals (and Jacobians if with_J) over the inliers; totals land in sh.red[0][*]
@@ -825,7 +826,12 @@ static __device__ void lm_eval(const DevBuffers& d, const SeqState& s, size_t o,
         if (lane == 0) sh.red[wv][k] = r;
     }
     __syncthreads();
-    if (threadIdx.x >= k0 && threadIdx.x < 28) sh.red[0][threadIdx.x] = sh.red[0][threadIdx.x] + sh.red[1][threadIdx.x] + sh.red[2][threadIdx.x] + sh.red[3][threadIdx.x];
+    if (threadIdx.x >= k0 && threadIdx.x < 28) {
+        double t = sh.red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < PF_WAVES; w++) t += sh.red[w][threadIdx.x];
+        sh.red[0][threadIdx.x] = t;
+    }
     __syncthreads();
 }
 
@@ -947,7 +953,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
     for (int k = 1; k < 64; k <<= 1) { int t = __shfl_up(incl, k); if (lane >= k) incl += t; }
     if (lane == 63) sh.wave_tot[wv] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < 4; i++) { int t = sh.wave_tot[i]; sh.wave_tot[i] = acc; acc += t; } sh.total = acc; }
+    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < PF_WAVES; i++) { int t = sh.wave_tot[i]; sh.wave_tot[i] = acc; acc += t; } sh.total = acc; }
     __syncthreads();
     const int n_inl = sh.total;
     if (threadIdx.x == 0) {
