@@ -90,17 +90,18 @@ class Bucket {                                                       // include/
     Bucket(int max_size_) : max_size(max_size_) {}
     int compute_score(const int age, const int strength) { return age + (strength - FAST_THRESHOLD) / 20; }
     void add_feature(const Point2f point, const int age, const int strength) {
-        // the insertion rule runs on the GPU: replay the recorded inputs through a 1x1 grid of this capacity
-        in_.points.push_back(point); in_.ages.push_back(age); in_.strengths.push_back(strength);
-        features = in_;
+        // the insertion rule (feature_set.cpp:20-53) runs on the GPU: the bucket's current content, in slot order, followed by
+        // the new feature goes through a 1x1 grid of this capacity — the stored features refill their slots in the same order
+        // (they passed the age test when they entered), then the new one meets exactly the state the reference's bucket is in.
+        // One call with at most max_size + 1 inputs per insertion (not a replay of everything ever offered).
+        if (!max_size) return;
+        features.points.push_back(point); features.ages.push_back(age); features.strengths.push_back(strength);
         float mx = 1;
-        for (auto& p : in_.points) { if (p.x > mx) mx = p.x; if (p.y > mx) mx = p.y; }
+        for (auto& p : features.points) { if (p.x > mx) mx = p.x; if (p.y > mx) mx = p.y; }
         Image dims(reinterpret_cast<const uint8_t*>(this), (int)mx + 2, (int)mx + 2);   // only rows/cols are read
-        if (max_size) features.filterByBucketLocationInternal(dims, 1, 1, 0, max_size); else features.clear();
+        features.filterByBucketLocationInternal(dims, 1, 1, 0, max_size);
     }
     int size() { return features.size(); }
-   private:
-    FeatureSet in_;
 };
 
 inline std::vector<Point2f> featureDetectionFast(const Image image, const int fast_threshold,

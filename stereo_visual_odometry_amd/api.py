@@ -204,31 +204,28 @@ class FeatureSet:
 
 
 class Bucket:
-    """vo.h:195-229.  add_feature records the call; the bucket's content is evaluated on the GPU by
-    replaying the recorded sequence through a 1x1 grid of capacity max_size (same insertion rule)."""
+    """vo.h:195-229.  add_feature applies the insertion rule (feature_set.cpp:20-53) on the GPU: the bucket's current content, in
+    slot order, followed by the new feature goes through a 1x1 grid of capacity max_size — the stored features refill their
+    slots in the same order, then the new one meets exactly the state the reference's bucket is in (at most max_size + 1
+    inputs per insertion)."""
 
     def __init__(self, max_size, device=0):
         self.max_size = max_size
         self.device = device
-        self._in = []
+        self.features = FeatureSet(device)
 
     def compute_score(self, age, strength):
         q = abs(strength - FAST_THRESHOLD) // 20
         return age + (q if strength >= FAST_THRESHOLD else -q)       # C++ int division truncates toward zero
 
     def add_feature(self, point, age, strength):
-        self._in.append((float(point[0]), float(point[1]), int(age), int(strength)))
-
-    @property
-    def features(self):
-        fs = FeatureSet(self.device)
-        if not self._in or not self.max_size:
-            return fs
-        a = np.array(self._in, np.float64)
-        fs.points = a[:, :2].astype(np.float32); fs.ages = a[:, 2].astype(np.int32); fs.strengths = a[:, 3].astype(np.int32)
-        side = int(max(2, np.ceil(a[:, :2].max()) + 1))
+        if not self.max_size:
+            return
+        fs = self.features
+        fs.points = np.concatenate([np.asarray(fs.points, np.float32).reshape(-1, 2), np.array([[point[0], point[1]]], np.float32)])
+        fs.ages = np.concatenate([fs.ages, np.array([age], np.int32)]); fs.strengths = np.concatenate([fs.strengths, np.array([strength], np.int32)])
+        side = int(max(2, np.ceil(fs.points.max()) + 1))
         fs.filterByBucketLocationInternal(np.zeros((side, side), np.uint8), 1, 1, 0, self.max_size)
-        return fs
 
     def size(self):
         return self.features.size()

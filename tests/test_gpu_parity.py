@@ -77,6 +77,20 @@ def test_ref_kat_bucket(api):
     assert f.size() == 3 and f.ages.tolist() == [6, 4, 5] and f.strengths.tolist() == [60, 40, 50]
 
 
+def test_bucket_incremental_equals_oracle_bucket(api):
+    """Bucket::add_feature one call at a time (content + newcomer through the GPU rule) against the oracle's Bucket over random
+    insertions: same slots in the same order after every call, incl. aged-out offers and score ties."""
+    rng = np.random.default_rng(5)
+    for cap in (1, 3, 6):
+        g, o = api.Bucket(cap), orc.Bucket(cap)
+        for k in range(40):
+            pt = (float(rng.integers(0, 50)), float(rng.integers(0, 50)))
+            age, st = int(rng.integers(0, 24)), int(rng.integers(0, 130))
+            g.add_feature(pt, age, st); o.add_feature(pt[0], pt[1], age, st)
+            assert g.size() == o.size()
+            assert g.features.ages.tolist() == o.ages and g.features.strengths.tolist() == o.strengths, (cap, k)
+
+
 def test_ref_kat_featureset(api):
     img = scenes.featureset_scene()
     fs = api.FeatureSet()
