@@ -143,8 +143,11 @@ void* svo_get_stream(svo_context* ctx);   /* hipStream_t the context launches on
 /* ------------------------------------------------------------------------------------------------
  * Stage-level entry points (host arrays in / out, one call = upload + kernel(s) + download).
  * They run the same kernels as the frame pipeline and exist so the reference's own unit tests
- * (src/main.cpp:50-264) and the parity tests can exercise each stage alone.
+ * (src/main.cpp:50-264) and the parity tests can exercise each stage alone.  Their device buffers are kept per calling thread
+ * and reused while device, image size and configuration stay the same; svo_stage_cache_clear() releases them.
  * ---------------------------------------------------------------------------------------------- */
+
+void svo_stage_cache_clear(void);
 
 /* replaces: featureDetectionFast(image, fast_threshold, response_strengths)  (vo.h:393-395, feature_set.cpp:55-68)
  * i.e. cv::FAST(.., nonmaxSuppression=true).  xy: cap x 2, resp: cap.  *n_out = total found (may exceed cap). */

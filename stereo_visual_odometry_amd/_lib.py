@@ -60,6 +60,8 @@ class SvoFrameStats(C.Structure):
 
 lib.svo_last_error.restype = C.c_char_p
 lib.svo_get_stream.restype = C.c_void_p
+lib.svo_stage_cache_clear.restype = None
+lib.svo_stage_cache_clear.argtypes = []
 lib.svo_get_stream.argtypes = [C.c_void_p]
 
 # every symbol include/svo.h declares (tests/test_abi.py checks the list against the header)
@@ -68,7 +70,7 @@ EXPORTS = [
     "svo_process_batch", "svo_process", "svo_circular_matching", "svo_submit_batch", "svo_collect", "svo_get_features", "svo_get_last_tracks",
     "svo_get_last_timing", "svo_get_stage_timing", "svo_get_stream", "svo_fast_detect", "svo_fast_score_map", "svo_bucket_filter",
     "svo_append_features_from_image", "svo_build_pyramid", "svo_lk_track", "svo_circular_match",
-    "svo_find_close_points", "svo_triangulate", "svo_camera_to_world", "svo_inverse_transform",
+    "svo_find_close_points", "svo_stage_cache_clear", "svo_triangulate", "svo_camera_to_world", "svo_inverse_transform",
 ]
 
 

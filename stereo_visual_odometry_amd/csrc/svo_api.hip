@@ -75,6 +75,7 @@ struct svo_context {
     int last_slot = -1;
     uint8_t* staging = nullptr;                  // device [2][B][W*H] for host-image calls
     uint8_t* h_staging = nullptr;                // pinned host mirror of `staging`
+    uint8_t* h_upload = nullptr;                 // pinned [6][W*H]: the stage entry points' image uploads (slot x camera)
     bool projection_set = false;
     int lk_grid = 0;
     int lk_hint = 0;                             // feature count seen in the last collected frame (sizes the LK grid; 0 = unknown)
@@ -211,6 +212,7 @@ extern "C" void svo_destroy(svo_context* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->staging) (void)hipFree(c->staging);
     if (c->h_staging) (void)hipHostFree(c->h_staging);
+    if (c->h_upload) (void)hipHostFree(c->h_upload);
     if (c->h_results) (void)hipHostFree(c->h_results);
     if (c->h_ptrs) (void)hipHostFree((void*)c->h_ptrs);
     for (int i = 0; i < SVO_RING; i++) {
@@ -542,9 +544,57 @@ static int use_device(int device) {
 
 struct CtxGuard { svo_context* c = nullptr; ~CtxGuard() { svo_destroy(c); } };
 
+// The stage entry points need a context's worth of device buffers (pyramid slots, track arrays, RANSAC workspaces).  Creating
+// and destroying one per call costs milliseconds of hipMalloc / hipFree, fine for a test and slow for a caller that uses them
+// as an API (e.g. calcOpticalFlowPyrLK per frame), so the last one is kept per thread and reused when device, image size and
+// configuration match and its capacity suffices.  Every call overwrites the whole sequence record, so nothing leaks from one
+// call into the next.  svo_stage_cache_clear() frees it (it is deliberately not freed at thread exit: the HIP runtime may be
+// gone by then).
+static bool cfg_equal(const svo_config& a, const svo_config& b) {
+    return a.bucket_start_row == b.bucket_start_row && a.buckets_along_height == b.buckets_along_height && a.buckets_along_width == b.buckets_along_width &&
+           a.features_per_bucket == b.features_per_bucket && a.features_threshold == b.features_threshold &&
+           a.pre_matching_feature_threshold == b.pre_matching_feature_threshold && a.age_threshold == b.age_threshold && a.fast_threshold == b.fast_threshold &&
+           a.ransac_reprojection_error == b.ransac_reprojection_error && a.ransac_iterations == b.ransac_iterations &&
+           a.optical_flow_min_eig_threshold == b.optical_flow_min_eig_threshold &&
+           a.circular_matching_success_threshold == b.circular_matching_success_threshold && a.max_translation_norm == b.max_translation_norm &&
+           a.max_rotation_norm == b.max_rotation_norm && a.win_w == b.win_w && a.win_h == b.win_h && a.max_level == b.max_level &&
+           a.lk_max_count == b.lk_max_count && a.lk_epsilon == b.lk_epsilon && a.ransac_confidence == b.ransac_confidence &&
+           a.max_features == b.max_features && a.channels == b.channels;
+}
+struct StageCache { svo_context* c = nullptr; svo_config cfg; int device = -1, w = 0, h = 0; };
+static thread_local StageCache g_stage;
+static int stage_ctx(const svo_config& cfg_in, int device, int w, int h, int cap, svo_context** out) {
+    svo_config cfg = cfg_in;
+    if (cfg.channels == 0) cfg.channels = 1;
+    StageCache& sc = g_stage;
+    if (sc.c && sc.device == device && sc.w == w && sc.h == h && cfg_equal(sc.cfg, cfg) && sc.c->d.CAP >= cap) {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamSynchronize(sc.c->stream));
+        *out = sc.c;
+        return SVO_OK;
+    }
+    if (sc.c) { svo_destroy(sc.c); sc.c = nullptr; }
+    int rc = ctx_create(&cfg, device, 1, w, h, cap, &sc.c);
+    if (rc != SVO_OK) { sc.c = nullptr; return rc; }
+    sc.cfg = cfg; sc.device = device; sc.w = w; sc.h = h;
+    *out = sc.c;
+    return SVO_OK;
+}
+extern "C" void svo_stage_cache_clear(void) {
+    if (g_stage.c) { svo_destroy(g_stage.c); g_stage.c = nullptr; }
+}
+
+// Level 0 of (slot, cam) <- a host image.  Rows are packed into pinned memory first: a 2-D copy from pageable memory degenerates
+// into per-row transfers (3.5 ms per 1241x376 image), the contiguous pinned copy takes ~20 us.  One pinned buffer per
+// (slot, camera), so the copies of one call never overwrite each other before they have run.
 static int upload_image(svo_context* c, int slot, int cam, const uint8_t* img, int stride) {
+    const size_t W = c->d.geom.W, H = c->d.geom.H;
+    if (!c->h_upload) HIPCHK(hipHostMalloc((void**)&c->h_upload, W * H * 6));
+    uint8_t* h = c->h_upload + W * H * (size_t)(slot * 2 + cam);
+    if ((size_t)stride == W) memcpy(h, img, W * H);
+    else for (size_t y = 0; y < H; y++) memcpy(h + y * W, img + y * (size_t)stride, W);
     uint8_t* dst = c->d.pyr + pyr_index(c->d, 0, slot, cam);
-    HIPCHK(hipMemcpy2DAsync(dst, c->d.geom.W, img, stride, c->d.geom.W, c->d.geom.H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dst, h, W * H, hipMemcpyHostToDevice, c->stream));
     return SVO_OK;
 }
 static int set_state(svo_context* c, const SeqState& hs) {
@@ -625,8 +675,7 @@ extern "C" int svo_append_features_from_image(int device, const svo_config* cfg_
     if (!img || !n_io || *n_io < 0 || stride < w || cap < *n_io) return fail_arg("bad arguments");
     svo_config cfg; if (cfg_in) cfg = *cfg_in; else svo_config_default(&cfg);
     cfg.channels = 1;                                                             // stage entry points are single-channel
-    CtxGuard g; int rc = ctx_create(&cfg, device, 1, w, h, *n_io, &g.c); if (rc != SVO_OK) return rc;
-    svo_context* c = g.c;
+    svo_context* c = nullptr; int rc = stage_ctx(cfg, device, w, h, *n_io, &c); if (rc != SVO_OK) return rc;
     const int n = *n_io;
     if (n > 0) {
         if (!xy || !ages || !strengths) return fail_arg("null arrays");
@@ -682,8 +731,7 @@ extern "C" int svo_lk_track(int device, const uint8_t* prev_img, const uint8_t* 
     svo_config cfg; svo_config_default(&cfg);
     cfg.win_w = cfg.win_h = win; cfg.max_level = max_level; cfg.lk_max_count = max_count; cfg.lk_epsilon = epsilon;
     cfg.optical_flow_min_eig_threshold = min_eig_threshold;
-    CtxGuard g; int rc = ctx_create(&cfg, device, 1, w, h, n, &g.c); if (rc != SVO_OK) return rc;
-    svo_context* c = g.c;
+    svo_context* c = nullptr; int rc = stage_ctx(cfg, device, w, h, n, &c); if (rc != SVO_OK) return rc;
     if (n == 0) return SVO_OK;
     if ((rc = upload_image(c, 0, 0, prev_img, stride)) != SVO_OK) return rc;
     if ((rc = upload_image(c, 1, 0, next_img, stride)) != SVO_OK) return rc;
@@ -706,8 +754,7 @@ extern "C" int svo_circular_match(int device, const svo_config* cfg_in, const ui
     if (n > 0 && (!pl0 || !pl1 || !pr1 || !pr0 || !pl0_circle || !ok)) return fail_arg("null arrays");
     svo_config cfg; if (cfg_in) cfg = *cfg_in; else svo_config_default(&cfg);
     cfg.max_features = 0; cfg.channels = 1;
-    CtxGuard g; int rc = ctx_create(&cfg, device, 1, w, h, n, &g.c); if (rc != SVO_OK) return rc;
-    svo_context* c = g.c;
+    svo_context* c = nullptr; int rc = stage_ctx(cfg, device, w, h, n, &c); if (rc != SVO_OK) return rc;
     if (n == 0) return SVO_OK;                                                    // vo.cpp:179-181
     if ((rc = upload_image(c, 0, 0, l0, stride)) != SVO_OK) return rc;
     if ((rc = upload_image(c, 0, 1, r0, stride)) != SVO_OK) return rc;
@@ -747,8 +794,7 @@ extern "C" int svo_find_close_points(int device, int n, const float* p1, const f
 extern "C" int svo_triangulate(int device, const float Pl[12], const float Pr[12], int n, const float* pts_l, const float* pts_r, float* xyz) {
     if (!Pl || !Pr || n < 0 || (n > 0 && (!pts_l || !pts_r || !xyz))) return fail_arg("bad arguments");
     svo_config cfg; svo_config_default(&cfg);
-    CtxGuard g; int rc = ctx_create(&cfg, device, 1, 64, 64, n, &g.c); if (rc != SVO_OK) return rc;
-    svo_context* c = g.c;
+    svo_context* c = nullptr; int rc = stage_ctx(cfg, device, 64, 64, n, &c); if (rc != SVO_OK) return rc;
     if (n == 0) return SVO_OK;
     SeqState hs; memset(&hs, 0, sizeof(hs));
     hs.active = 1; hs.fail_reason = 0; hs.n_tracks = n;
@@ -774,8 +820,7 @@ extern "C" int svo_camera_to_world(int device, const float K[9], int n, const fl
     cfg.ransac_reprojection_error = reproj_error; cfg.ransac_confidence = confidence;
     cfg.features_threshold = 0;                                                  // cameraToWorld itself has no inlier-count gate
     cfg.max_translation_norm = 1e300; cfg.max_rotation_norm = 1e300;             // nor motion gates
-    CtxGuard g; int rc = ctx_create(&cfg, device, 1, 64, 64, n, &g.c); if (rc != SVO_OK) return rc;
-    svo_context* c = g.c;
+    svo_context* c = nullptr; int rc = stage_ctx(cfg, device, 64, 64, n, &c); if (rc != SVO_OK) return rc;
     SeqState hs; memset(&hs, 0, sizeof(hs));
     hs.active = 1; hs.fail_reason = 0; hs.n_tracks = n; hs.n_feat = n; hs.feat_buf = 0;
     memcpy(hs.K, K, sizeof(float) * 9); memcpy(hs.R, R, sizeof(double) * 9); memcpy(hs.t, t, sizeof(double) * 3);
