@@ -220,7 +220,7 @@ def main():
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = dt_local = time.perf_counter() - t0
     if grouped:
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -341,6 +341,11 @@ def main():
                          "kernel_avg_ms": lk_avg_ms, "frame_avg_ms": float(np.mean(fr_ms)),
                          "whole_frame_frac": bytes_total * value / world / 1e9 / PEAK_HBM_GBS},
             "cpu_baseline": cpu, "ate": ate,
+            # the line's own proof that the device worked through the timed region (an smi sampler misses a region this short):
+            # the LK launches' HIP-event durations of rank 0, summed, against rank 0's wall clock; launches of different contexts
+            # run on different streams, so their tails may overlap and the share is an upper estimate of LK's part
+            "device_busy": {"lk_kernel_ms_in_timed_region": float(np.sum(lk_ms)), "lk_launches": len(lk_ms),
+                            "timed_region_ms": dt_local * 1e3, "lk_share_of_timed_region": float(np.sum(lk_ms)) / (dt_local * 1e3)},
         }
         print(json.dumps(out))
     if grouped:

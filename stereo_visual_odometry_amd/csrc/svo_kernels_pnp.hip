@@ -199,8 +199,8 @@ void launch_pnp_subsets(const DevBuffers& d, hipStream_t st) {
 // round-robin order: the 6 pairs of a round are disjoint, so lanes 0..5 rotate them in parallel and the result is
 // bit-identical to the sequential round-robin loop.  The three beta approximations (N = 4, 2, 3 null vectors) are
 // independent after L and rho and run on lanes 0..2.
-#define EP_G 8                                   // lanes per hypothesis
-#define EP_HPB 8                                 // hypotheses per block
+#define EP_G 8                                   // lanes per hypothesis, many sequences (k_pnp_epnp_lean); 64 / EP_G hypotheses per block
+#define EP_G_LONE 16                             // lanes per hypothesis when few sequences run (k_pnp_epnp): see rotate_pair12_sides
 #define EP_STRIDE 1032                           // doubles per hypothesis (+8 pad: distinct LDS banks per hypothesis)
 // arena map (doubles)
 #define EA_AT 0                                  // 144  MtM, then the rotating rows
@@ -253,6 +253,42 @@ static __device__ bool rotate_pair12(double* At, double* Wv, double* Vt, int i, 
         double t1 = -s * Vi[k] + c * Vj[k];
         Vi[k] = t0; Vj[k] = t1;
     }
+    return true;
+}
+
+// The same rotation with the work of one pair on TWO lanes: both compute p, c and s from the rows of At (identical bits), then one
+// rotates the rows of At and sums the new squared norms, the other rotates the rows of Vt — one instruction stream, half the
+// rotation work on the critical path of a lone stream.  The lanes of a pair sit in one wave: every read of At for p precedes, in
+// program order, the first write of the rotated rows.
+static __device__ bool rotate_pair12_sides(double* At, double* Wv, double* Vt, int i, int j, bool vside) {
+    const double eps = SVO_DBL_EPS * 10;
+    const double* Ai = At + i * 12; const double* Aj = At + j * 12;
+    double a = Wv[i], p = 0, b = Wv[j], c, s;
+    for (int k = 0; k < 12; k++) p += Ai[k] * Aj[k];
+    if (fabs(p) <= eps * sqrt(a * b)) return false;
+    p *= 2;
+    double beta = a - b, gamma = sqrt(p * p + beta * beta);
+    if (beta < 0) {
+        double delta = (gamma - beta) * 0.5;
+        s = sqrt(delta / gamma);
+        c = p / (gamma * s * 2);
+    } else {
+        c = sqrt((gamma + beta) / (gamma * 2));
+        s = p / (gamma * c * 2);
+    }
+    double* X = (vside ? Vt : At) + i * 12; double* Y = (vside ? Vt : At) + j * 12;
+    double x[12], y[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) { x[k] = X[k]; y[k] = Y[k]; }
+    a = b = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        double t0 = c * x[k] + s * y[k];
+        double t1 = -s * x[k] + c * y[k];
+        X[k] = t0; Y[k] = t1;
+        a += t0 * t0; b += t1 * t1;
+    }
+    if (!vside) { Wv[i] = a; Wv[j] = b; }
     return true;
 }
 
@@ -450,7 +486,7 @@ static __device__ void epnp_setup(double* ar, double fu, double fv, double uc, d
             a[0] = 1.0 - a[1] - a[2] - a[3];
         }
     }
-    double* M = ar + EA_M; double* MtM = ar + EA_AT; double* Vt = ar + EA_VT; double* Wv = ar + EA_W;
+    double* M = ar + EA_M;
 #pragma unroll 1
     for (int i = 0; i < n; i++) {
         double* M1 = M + 24 * i; double* M2 = M1 + 12; const double* as = alphas + 4 * i;
@@ -460,70 +496,89 @@ static __device__ void epnp_setup(double* ar, double fu, double fv, double uc, d
             M2[3 * j] = 0.0; M2[3 * j + 1] = as[j] * fv; M2[3 * j + 2] = as[j] * (vc - v);
         }
     }
-#pragma unroll 1
-    for (int i = 0; i < 12; i++)
-#pragma unroll 1
-        for (int j = i; j < 12; j++) {
-            double s = 0;
-            for (int k = 0; k < 2 * n; k++) s += M[12 * k + i] * M[12 * k + j];
-            MtM[12 * i + j] = MtM[12 * j + i] = s;
-        }
-    // MtM is exactly symmetric, i.e. its own transpose: the one-sided Jacobi runs in place on it
-#pragma unroll 1
-    for (int i = 0; i < 12; i++) {
-        double sd = 0;
-        for (int k = 0; k < 12; k++) { double tt = MtM[i * 12 + k]; sd += tt * tt; }
-        Wv[i] = sd;
-        for (int k = 0; k < 12; k++) Vt[i * 12 + k] = 0;
-        Vt[i * 12 + i] = 1;
-    }
 }
 
-// phase 3 (one lane): singular values, the descending selection sort applied to Vt, then L (6x10) and rho
-static __device__ void epnp_sort_and_L(double* ar) {
-    double* At = ar + EA_AT; double* Vt = ar + EA_VT; double* Wv = ar + EA_W; double* cws = ar + EA_CWS;
-#pragma unroll 1
-    for (int i = 0; i < 12; i++) {
-        double sd = 0;
-        for (int k = 0; k < 12; k++) { double tt = At[i * 12 + k]; sd += tt * tt; }
-        Wv[i] = sqrt(sd);
+// phase 1b (one lane per row i): row i of MtM = M^T M (each entry summed over the 10 rows of M in order; the products commute, so
+// entry (i, j) and entry (j, i) are the same bits: MtM is exactly symmetric, i.e. its own transpose, and the one-sided Jacobi
+// runs in place on it), its squared norm, and row i of Vt = I.
+static __device__ void epnp_setup_row(double* ar, int i) {
+    const double* M = ar + EA_M; double* MtM = ar + EA_AT; double* Vt = ar + EA_VT; double* Wv = ar + EA_W;
+    double mi[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) mi[k] = M[12 * k + i];
+    double sd = 0;
+#pragma unroll 2
+    for (int j = 0; j < 12; j++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 10; k++) s += M[12 * k + j] * mi[k];
+        MtM[12 * i + j] = s;
+        sd += s * s;
+        Vt[i * 12 + j] = i == j ? 1.0 : 0.0;
     }
-#pragma unroll 1
+    Wv[i] = sd;
+}
+
+// phase 3, spread over the lanes of the hypothesis (the caller separates the steps with barriers):
+//   a (lane per row)   singular values = row norms of the rotated MtM
+//   b (one lane)       the descending selection sort (the FIRST maximum wins ties), on (value, row) pairs
+//   c (lanes 0..3)     the four rows of Vt everything after this reads — the sorted rows 11, 10, 9, 8 — move into place
+//   d (lanes 0..3)     differences of the control points of null vector i;   e (lanes 0..5 + one) L (6x10) row by row, rho
+static __device__ void epnp_row_norm(double* ar, int i) {
+    const double* At = ar + EA_AT;
+    double sd = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) { double tt = At[i * 12 + k]; sd += tt * tt; }
+    ar[EA_W + i] = sqrt(sd);
+}
+static __device__ void epnp_sort_rows(double* ar) {
+    double w[12]; int id[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) { w[i] = ar[EA_W + i]; id[i] = i; }
+#pragma unroll
     for (int i = 0; i < 11; i++) {
-        int j = i;
-        for (int k = i + 1; k < 12; k++) if (Wv[j] < Wv[k]) j = k;
-        if (i != j) {
-            double tt = Wv[i]; Wv[i] = Wv[j]; Wv[j] = tt;
-            for (int k = 0; k < 12; k++) { tt = Vt[i * 12 + k]; Vt[i * 12 + k] = Vt[j * 12 + k]; Vt[j * 12 + k] = tt; }
-        }
+        // position i takes the first maximum of w[i..11]; the displaced pair goes where the maximum was
+        double best = w[i]; int bj = i;
+#pragma unroll
+        for (int k = i + 1; k < 12; k++) if (best < w[k]) { best = w[k]; bj = k; }
+        const double wi = w[i]; const int ii = id[i];
+        int bid = ii;
+#pragma unroll
+        for (int k = i + 1; k < 12; k++) if (k == bj) { bid = id[k]; w[k] = wi; id[k] = ii; }
+        w[i] = best; id[i] = bid;
     }
-    double* L = ar + EA_L; double* rho = ar + EA_RHO;
-    double* dv = At;                               // 4 x 6 x 3 scratch in the dead At region
-    for (int i = 0; i < 4; i++) {
-        const double* v = Vt + 12 * (11 - i);
-        int a = 0, b = 1;
-        for (int j = 0; j < 6; j++) {
-            for (int k = 0; k < 3; k++) dv[(i * 6 + j) * 3 + k] = v[3 * a + k] - v[3 * b + k];
-            b++;
-            if (b > 3) { a++; b = a + 1; }
-        }
+    int* src = (int*)(ar + EA_M);                                     // M is dead
+    src[0] = id[11]; src[1] = id[10]; src[2] = id[9]; src[3] = id[8];
+}
+static __device__ void epnp_null_vector_diffs(double* ar, int i) {
+    const double* v = ar + EA_VT + 12 * (11 - i);
+    double* dv = ar + EA_AT;                                          // 4 x 6 x 3 scratch in the dead At region
+    int a = 0, b = 1;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        for (int k = 0; k < 3; k++) dv[(i * 6 + j) * 3 + k] = v[3 * a + k] - v[3 * b + k];
+        b++;
+        if (b > 3) { a++; b = a + 1; }
     }
-#pragma unroll 1
-    for (int i = 0; i < 6; i++) {
-        double* row = L + 10 * i;
-        const double* d0 = dv + (0 * 6 + i) * 3; const double* d1 = dv + (1 * 6 + i) * 3;
-        const double* d2 = dv + (2 * 6 + i) * 3; const double* d3 = dv + (3 * 6 + i) * 3;
-        row[0] = dot3(d0, d0);
-        row[1] = 2.0 * dot3(d0, d1);
-        row[2] = dot3(d1, d1);
-        row[3] = 2.0 * dot3(d0, d2);
-        row[4] = 2.0 * dot3(d1, d2);
-        row[5] = dot3(d2, d2);
-        row[6] = 2.0 * dot3(d0, d3);
-        row[7] = 2.0 * dot3(d1, d3);
-        row[8] = 2.0 * dot3(d2, d3);
-        row[9] = dot3(d3, d3);
-    }
+}
+static __device__ void epnp_L_row(double* ar, int i) {
+    const double* dv = ar + EA_AT;
+    double* row = ar + EA_L + 10 * i;
+    const double* d0 = dv + (0 * 6 + i) * 3; const double* d1 = dv + (1 * 6 + i) * 3;
+    const double* d2 = dv + (2 * 6 + i) * 3; const double* d3 = dv + (3 * 6 + i) * 3;
+    row[0] = dot3(d0, d0);
+    row[1] = 2.0 * dot3(d0, d1);
+    row[2] = dot3(d1, d1);
+    row[3] = 2.0 * dot3(d0, d2);
+    row[4] = 2.0 * dot3(d1, d2);
+    row[5] = dot3(d2, d2);
+    row[6] = 2.0 * dot3(d0, d3);
+    row[7] = 2.0 * dot3(d1, d3);
+    row[8] = 2.0 * dot3(d2, d3);
+    row[9] = dot3(d3, d3);
+}
+static __device__ void epnp_rho(double* ar) {
+    const double* cws = ar + EA_CWS; double* rho = ar + EA_RHO;
     rho[0] = dist2(cws, cws + 3); rho[1] = dist2(cws, cws + 6); rho[2] = dist2(cws, cws + 9);
     rho[3] = dist2(cws + 3, cws + 6); rho[4] = dist2(cws + 3, cws + 9); rho[5] = dist2(cws + 6, cws + 9);
 }
@@ -564,15 +619,17 @@ static __device__ void epnp_branch(double* ar, int branch, double fu, double fv,
 
 // Hypotheses [h0, h1).  The first chunk (h0 == 0) is always solved; later chunks only up to s.pnp_need, the bound the
 // adaptive loop had reached after the first chunk (the bound only ever shrinks, so nothing beyond it can be consulted).
+template <int G>                          // lanes per hypothesis: 8 (six rotate a pair each, At and Vt) or 16 (twelve: At and Vt on separate lanes)
 static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0, int h1, double* arena) {
+    constexpr int HPB = 64 / G;
     const int seq = blockIdx.y;
     const SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
     int hend = h0 > 0 ? (s.pnp_need < h1 ? s.pnp_need : h1) : h1;
     if (s.n_tracks == 5 && hend > 1) hend = 1;                          // five points: a single direct EPnP, no RANSAC
-    if (h0 + (int)blockIdx.x * EP_HPB >= hend) return;                  // block-uniform
-    const int g = threadIdx.x / EP_G, q = threadIdx.x % EP_G;
-    const int h = h0 + blockIdx.x * EP_HPB + g;
+    if (h0 + (int)blockIdx.x * HPB >= hend) return;                     // block-uniform
+    const int g = threadIdx.x / G, q = threadIdx.x % G;
+    const int h = h0 + blockIdx.x * HPB + g;
     const bool valid = h < hend;
     double* ar = arena + g * EP_STRIDE;
     const double fx = s.K[0], fy = s.K[4], cx = s.K[2], cy = s.K[5];
@@ -591,25 +648,48 @@ static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0
         epnp_setup(ar, fx, fy, cx, cy);
     }
     __syncthreads();
+    if (valid) for (int i = q; i < 12; i += G) epnp_setup_row(ar, i);
+    __syncthreads();
     // ---- 12 x 12 one-sided Jacobi, round-robin ordering: lane q < 6 owns pair q of every round
     bool done = !valid;
     for (int iter = 0; iter < 30; iter++) {
         bool changed = false;
         for (int r = 0; r < 11; r++) {
-            if (!done && q < 6) {
-                int pa = q == 0 ? 0 : 1 + (q - 1 + r) % 11;
-                int pb = 1 + (10 - q + r) % 11;
+            const int qp = G == 16 ? (q & 7) : q;                       // the pair of the round this lane works on
+            if (!done && qp < 6) {
+                int pa = qp == 0 ? 0 : 1 + (qp - 1 + r) % 11;
+                int pb = 1 + (10 - qp + r) % 11;
                 int i = pa < pb ? pa : pb, j = pa < pb ? pb : pa;
-                changed |= rotate_pair12(ar + EA_AT, ar + EA_W, ar + EA_VT, i, j);
+                if (G == 16) changed |= rotate_pair12_sides(ar + EA_AT, ar + EA_W, ar + EA_VT, i, j, q >= 8);
+                else changed |= rotate_pair12(ar + EA_AT, ar + EA_W, ar + EA_VT, i, j);
             }
             __syncthreads();
         }
         const unsigned long long m = __ballot(changed);
-        if (((m >> (g * EP_G)) & 0xFFull) == 0) done = true;            // this hypothesis converged (no pair rotated in the sweep)
+        if (((m >> (g * G)) & ((1ull << G) - 1)) == 0) done = true;            // this hypothesis converged (no pair rotated in the sweep)
         if (__ballot(!done) == 0ull) break;
     }
     __syncthreads();
-    if (valid && q == 0) epnp_sort_and_L(ar);
+    if (valid) for (int i = q; i < 12; i += G) epnp_row_norm(ar, i);
+    __syncthreads();
+    if (valid && q == 0) epnp_sort_rows(ar);
+    __syncthreads();
+    {
+        double row[12];
+        const bool mover = valid && q < 4;
+        if (mover) { const double* sp = ar + EA_VT + 12 * ((const int*)(ar + EA_M))[q];
+#pragma unroll
+            for (int k = 0; k < 12; k++) row[k] = sp[k]; }
+        __syncthreads();
+        if (mover) { double* dp = ar + EA_VT + 12 * (11 - q);
+#pragma unroll
+            for (int k = 0; k < 12; k++) dp[k] = row[k]; }
+    }
+    __syncthreads();
+    if (valid && q < 4) epnp_null_vector_diffs(ar, q);
+    __syncthreads();
+    if (valid && q < 6) epnp_L_row(ar, q);
+    if (valid && q == 6) epnp_rho(ar);
     __syncthreads();
     if (valid && q < 3) epnp_branch(ar, q + 1, fx, fy, cx, cy);
     __syncthreads();
@@ -628,13 +708,13 @@ static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0
 // form when a single stream runs alone (latency), but with many sequences its waves sit beside the other context's LK waves,
 // and every 104 registers they hold is one LK wave less per SIMD.  The lean build is limited to the architected 128 VGPRs
 // (+ AGPR spill space, 257 in all): measured +2.4 % whole-job rate at 256 sequences, same results.
-__global__ __launch_bounds__(EP_G * EP_HPB) void k_pnp_epnp(DevBuffers d, int h0, int h1) {
-    __shared__ double arena[EP_HPB * EP_STRIDE];
-    pnp_epnp_body(d, h0, h1, arena);
+__global__ __launch_bounds__(64) void k_pnp_epnp(DevBuffers d, int h0, int h1) {
+    __shared__ double arena[(64 / EP_G_LONE) * EP_STRIDE];
+    pnp_epnp_body<EP_G_LONE>(d, h0, h1, arena);
 }
-__global__ __launch_bounds__(EP_G * EP_HPB) __attribute__((amdgpu_num_vgpr(128))) void k_pnp_epnp_lean(DevBuffers d, int h0, int h1) {
-    __shared__ double arena[EP_HPB * EP_STRIDE];
-    pnp_epnp_body(d, h0, h1, arena);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_pnp_epnp_lean(DevBuffers d, int h0, int h1) {
+    __shared__ double arena[(64 / EP_G) * EP_STRIDE];
+    pnp_epnp_body<EP_G>(d, h0, h1, arena);
 }
 
 // ------------------------------------------------------------------------------------------------ hypothesis scoring
@@ -1233,13 +1313,14 @@ void launch_pnp(const DevBuffers& d, hipStream_t st) {
     // the subsets were drawn by the last block of k_triangulate (stage entry points go through launch_triangulate too)
     const int c0 = pnp_first_chunk(d);
     const bool lean = d.B > 8;                                       // see k_pnp_epnp_lean
-    if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, 0, c0);
-    else hipLaunchKernelGGL(k_pnp_epnp, dim3((c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, 0, c0);
+    const int hpb = 64 / (lean ? EP_G : EP_G_LONE);
+    if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((c0 + hpb - 1) / hpb, d.B), dim3(64), 0, st, d, 0, c0);
+    else hipLaunchKernelGGL(k_pnp_epnp, dim3((c0 + hpb - 1) / hpb, d.B), dim3(64), 0, st, d, 0, c0);
     hipLaunchKernelGGL(k_pnp_score, dim3(c0, d.B), dim3(256), 0, st, d, 0, c0);
     if (d.K > c0) {
         hipLaunchKernelGGL(k_pnp_decide, dim3((d.B + 63) / 64), dim3(64), 0, st, d, c0);
-        if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((d.K - c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, c0, d.K);
-        else hipLaunchKernelGGL(k_pnp_epnp, dim3((d.K - c0 + EP_HPB - 1) / EP_HPB, d.B), dim3(EP_G * EP_HPB), 0, st, d, c0, d.K);
+        if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((d.K - c0 + hpb - 1) / hpb, d.B), dim3(64), 0, st, d, c0, d.K);
+        else hipLaunchKernelGGL(k_pnp_epnp, dim3((d.K - c0 + hpb - 1) / hpb, d.B), dim3(64), 0, st, d, c0, d.K);
         hipLaunchKernelGGL(k_pnp_score, dim3(d.K - c0, d.B), dim3(256), 0, st, d, c0, d.K);
     }
     hipLaunchKernelGGL(k_pnp_final, dim3(d.B), dim3(PF_THREADS), 0, st, d);
