@@ -35,14 +35,7 @@ static __device__ __forceinline__ bool svd4_rotate(double (&At)[4][4], double (&
     if (fabs(p) <= eps * sqrt(a * b)) return false;
     p *= 2;
     double beta = a - b, gamma = sqrt(p * p + beta * beta);
-    if (beta < 0) {
-        double delta = (gamma - beta) * 0.5;
-        s = sqrt(delta / gamma);
-        c = p / (gamma * s * 2);
-    } else {
-        c = sqrt((gamma + beta) / (gamma * 2));
-        s = p / (gamma * c * 2);
-    }
+    jacobi_cs(p, beta, gamma, c, s);
     a = b = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -231,14 +224,7 @@ static __device__ bool rotate_pair12(double* At, double* Wv, double* Vt, int i, 
     if (fabs(p) <= eps * sqrt(a * b)) return false;
     p *= 2;
     double beta = a - b, gamma = sqrt(p * p + beta * beta);
-    if (beta < 0) {
-        double delta = (gamma - beta) * 0.5;
-        s = sqrt(delta / gamma);
-        c = p / (gamma * s * 2);
-    } else {
-        c = sqrt((gamma + beta) / (gamma * 2));
-        s = p / (gamma * c * 2);
-    }
+    jacobi_cs(p, beta, gamma, c, s);
     a = b = 0;
     for (int k = 0; k < 12; k++) {
         double t0 = c * Ai[k] + s * Aj[k];
@@ -268,14 +254,7 @@ static __device__ bool rotate_pair12_sides(double* At, double* Wv, double* Vt, i
     if (fabs(p) <= eps * sqrt(a * b)) return false;
     p *= 2;
     double beta = a - b, gamma = sqrt(p * p + beta * beta);
-    if (beta < 0) {
-        double delta = (gamma - beta) * 0.5;
-        s = sqrt(delta / gamma);
-        c = p / (gamma * s * 2);
-    } else {
-        c = sqrt((gamma + beta) / (gamma * 2));
-        s = p / (gamma * c * 2);
-    }
+    jacobi_cs(p, beta, gamma, c, s);
     double* X = (vside ? Vt : At) + i * 12; double* Y = (vside ? Vt : At) + j * 12;
     double x[12], y[12];
 #pragma unroll

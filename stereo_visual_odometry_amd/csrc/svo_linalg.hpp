@@ -16,6 +16,20 @@ template <int STRIDE> struct LdsVec {
     __device__ __forceinline__ LdsVec operator+(int off) const { return LdsVec{base + off * STRIDE}; }
 };
 
+// c and s of one Hestenes rotation (OpenCV's JacobiSVDImpl_): two arithmetically different forms, chosen by the sign of beta.
+// The lanes of a wave disagree about that sign, so written as if / else the wave walks BOTH division -> square root -> division
+// chains one after the other (~90 dependent f64 instructions instead of ~45).  Here the two forms share one instruction stream:
+// the same operations on selected operands, the same bits.
+__device__ __forceinline__ void jacobi_cs(double p, double beta, double gamma, double& c, double& s) {
+    const bool neg = beta < 0;
+    const double num = neg ? (gamma - beta) * 0.5 : gamma + beta;
+    const double den = neg ? gamma : gamma * 2;
+    const double r = sqrt(num / den);
+    const double o = p / (gamma * r * 2);
+    c = neg ? o : r;
+    s = neg ? r : o;
+}
+
 template <int M, int N, typename PA = double*, typename PW = double*>
 __device__ void jacobi_svd(PA At, PW Wv, PA Vt, int n1) {
     const double eps = SVO_DBL_EPS * 10, minval = SVO_DBL_MIN;
@@ -40,14 +54,7 @@ __device__ void jacobi_svd(PA At, PW Wv, PA Vt, int n1) {
                 if (fabs(p) <= eps * sqrt(a * b)) continue;
                 p *= 2;
                 double beta = a - b, gamma = sqrt(p * p + beta * beta);
-                if (beta < 0) {
-                    double delta = (gamma - beta) * 0.5;
-                    s = sqrt(delta / gamma);
-                    c = p / (gamma * s * 2);
-                } else {
-                    c = sqrt((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
-                }
+                jacobi_cs(p, beta, gamma, c, s);
                 a = b = 0;
                 for (int k = 0; k < M; k++) {
                     double t0 = c * Ai[k] + s * Aj[k];
@@ -118,14 +125,7 @@ __device__ __forceinline__ void jacobi_svd_reg(double (&At)[N][M], double (&Wv)[
                 if (fabs(p) <= eps * sqrt(a * b)) continue;
                 p *= 2;
                 double beta = a - b, gamma = sqrt(p * p + beta * beta);
-                if (beta < 0) {
-                    double delta = (gamma - beta) * 0.5;
-                    s = sqrt(delta / gamma);
-                    c = p / (gamma * s * 2);
-                } else {
-                    c = sqrt((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
-                }
+                jacobi_cs(p, beta, gamma, c, s);
                 a = b = 0;
 #pragma unroll
                 for (int k = 0; k < M; k++) {
