@@ -247,27 +247,48 @@ static __device__ bool rotate_pair12(double* At, double* Wv, double* Vt, int i, 
 // rotation work on the critical path of a lone stream.  The lanes of a pair sit in one wave: every read of At for p precedes, in
 // program order, the first write of the rotated rows.
 static __device__ bool rotate_pair12_sides(double* At, double* Wv, double* Vt, int i, int j, bool vside) {
+    // A lone wave per SIMD hides no latency: every dependent f64 instruction waits for its operand (~8 cycles against 4 to issue).
+    // The compiler orders for register pressure, not for this, so the order is pinned with sched_barrier: independent products
+    // first, and the rotation software-pipelined (products of element k, sums of k-1, squares of k-2, norms of k-3 per step).
     const double eps = SVO_DBL_EPS * 10;
-    const double* Ai = At + i * 12; const double* Aj = At + j * 12;
+    const int oi = __mul24(i, 12), oj = __mul24(j, 12);               // (a full 32-bit multiply is a quarter-rate instruction)
+    const double* Ai = At + oi; const double* Aj = At + oj;
     double a = Wv[i], p = 0, b = Wv[j], c, s;
-    for (int k = 0; k < 12; k++) p += Ai[k] * Aj[k];
-    if (fabs(p) <= eps * sqrt(a * b)) return false;
+    double ai[12], aj[12], pr[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) { ai[k] = Ai[k]; aj[k] = Aj[k]; }
+    __builtin_amdgcn_sched_barrier(0);
+    const double lim = eps * sqrt(a * b);                             // while the rows arrive from LDS
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 12; k++) pr[k] = ai[k] * aj[k];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 12; k++) p += pr[k];
+    if (fabs(p) <= lim) return false;
     p *= 2;
     double beta = a - b, gamma = sqrt(p * p + beta * beta);
     jacobi_cs(p, beta, gamma, c, s);
-    double* X = (vside ? Vt : At) + i * 12; double* Y = (vside ? Vt : At) + j * 12;
+    double* X = (vside ? Vt : At) + oi; double* Y = (vside ? Vt : At) + oj;
     double x[12], y[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) { x[k] = X[k]; y[k] = Y[k]; }
+    double ma[12], mb[12], mc[12], md[12], t0[12], t1[12], q0[12], q1[12];
     a = b = 0;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 12; k++) {
-        double t0 = c * x[k] + s * y[k];
-        double t1 = -s * x[k] + c * y[k];
-        X[k] = t0; Y[k] = t1;
-        a += t0 * t0; b += t1 * t1;
+    for (int st = 0; st < 15; st++) {
+        if (st < 12) { ma[st] = c * x[st]; mb[st] = s * y[st]; mc[st] = -s * x[st]; md[st] = c * y[st]; }
+        if (st >= 1 && st < 13) { t0[st - 1] = ma[st - 1] + mb[st - 1]; t1[st - 1] = mc[st - 1] + md[st - 1]; }
+        if (st >= 2 && st < 14) { q0[st - 2] = t0[st - 2] * t0[st - 2]; q1[st - 2] = t1[st - 2] * t1[st - 2]; }
+        if (st >= 3) { a += q0[st - 3]; b += q1[st - 3]; }
+        if (st >= 2 && st < 14 && ((st - 2) & 1)) {
+            X[st - 3] = t0[st - 3]; X[st - 2] = t0[st - 2]; Y[st - 3] = t1[st - 3]; Y[st - 2] = t1[st - 2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if (!vside) { Wv[i] = a; Wv[j] = b; }
+    double* Wo = vside ? At + EA_M : Wv;                              // Vt's lanes compute the sums as well (one stream) and drop them in dead space
+    Wo[i] = a; Wo[j] = b;
     return true;
 }
 
@@ -631,14 +652,17 @@ static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0
     __syncthreads();
     // ---- 12 x 12 one-sided Jacobi, round-robin ordering: lane q < 6 owns pair q of every round
     bool done = !valid;
+    const int qp = G == 16 ? (q & 7) : q;                               // the pair of the round this lane works on
+    // round r pairs row pa = 1 + (qp - 1 + r) % 11 (row 0 for pair 0) with row pb = 1 + (10 - qp + r) % 11: both walk the
+    // cycle 1..11 one step per round and are back where they started after the 11 rounds of a sweep
+    int pa = qp, pb = 11 - qp;
     for (int iter = 0; iter < 30; iter++) {
         bool changed = false;
         for (int r = 0; r < 11; r++) {
-            const int qp = G == 16 ? (q & 7) : q;                       // the pair of the round this lane works on
+            const int i = pa < pb ? pa : pb, j = pa < pb ? pb : pa;
+            pa = qp == 0 ? 0 : pa == 11 ? 1 : pa + 1;
+            pb = pb == 11 ? 1 : pb + 1;
             if (!done && qp < 6) {
-                int pa = qp == 0 ? 0 : 1 + (qp - 1 + r) % 11;
-                int pb = 1 + (10 - qp + r) % 11;
-                int i = pa < pb ? pa : pb, j = pa < pb ? pb : pa;
                 if (G == 16) changed |= rotate_pair12_sides(ar + EA_AT, ar + EA_W, ar + EA_VT, i, j, q >= 8);
                 else changed |= rotate_pair12(ar + EA_AT, ar + EA_W, ar + EA_VT, i, j);
             }
