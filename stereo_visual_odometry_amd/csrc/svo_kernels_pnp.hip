@@ -860,56 +860,104 @@ struct LmShared {
     int wave_tot[PF_WAVES]; int total;
 };
 
-// one evaluation of residuals (and Jacobians if with_J) over the inliers; totals land in sh.red[0][*]
-static __device__ void lm_eval(const DevBuffers& d, const SeqState& s, size_t o, int n, bool with_J, LmShared& sh) {
-    if (threadIdx.x == 0) rodrigues_to_matrix(sh.param, sh.R, with_J ? sh.dRdr : nullptr);
+// ---- wave-level sums of 28 doubles per lane, by transposition: each step halves the number of registers while doubling the
+// lanes summed into them (v_permlane32_swap / v_permlane16_swap across the rows of 16, DPP mirrors inside a row), so the wave does
+// ~30 additions instead of 28 x 6.  At the end lane l holds the wave total of ONE value, lm_red_slot(l) (or a duplicate: -1).
+static __device__ __forceinline__ double lm_fold32(double a, double b) {
+    int al = __double2loint(a), ah = __double2hiint(a), bl = __double2loint(b), bh = __double2hiint(b);
+    const auto rl = __builtin_amdgcn_permlane32_swap((unsigned)al, (unsigned)bl, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap((unsigned)ah, (unsigned)bh, false, false);
+    return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);   // lanes < 32: a, the others: b
+}
+static __device__ __forceinline__ double lm_fold16(double a, double b) {
+    int al = __double2loint(a), ah = __double2hiint(a), bl = __double2loint(b), bh = __double2hiint(b);
+    const auto rl = __builtin_amdgcn_permlane16_swap((unsigned)al, (unsigned)bl, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap((unsigned)ah, (unsigned)bh, false, false);
+    return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);   // even rows: a, odd rows: b
+}
+template <int CTRL> static __device__ __forceinline__ double lm_fold_row(double a, double b, bool upper) {
+    const double keep = upper ? b : a, send = upper ? a : b;
+    return keep + dpp_f64_t<CTRL>(send);
+}
+static __device__ __forceinline__ double lm_wave_sums28(const double (&acc)[28], int lane) {
+    double w[14], u[7], x[4], y[2];
+#pragma unroll
+    for (int k = 0; k < 14; k++) w[k] = lm_fold32(acc[k], acc[k + 14]);      // lanes < 32: value k, lanes >= 32: value k + 14
+#pragma unroll
+    for (int k = 0; k < 7; k++) u[k] = lm_fold16(w[k], w[k + 7]);            // row r: value k + 7 r
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+    for (int k = 0; k < 3; k++) x[k] = lm_fold_row<0x140>(u[k], u[k + 4], b3);   // row_mirror: lanes 8..15 of a row take u[k + 4]
+    x[3] = u[3] + dpp_f64_t<0x140>(u[3]);                                     // the odd one out: both halves hold it
+    y[0] = lm_fold_row<0x141>(x[0], x[2], b2);                                // row_half_mirror
+    y[1] = lm_fold_row<0x141>(x[1], x[3], b2);
+    double z = lm_fold_row<0x4E>(y[0], y[1], b1);                             // quad_perm [2,3,0,1]
+    return z + dpp_f64_t<0xB1>(z);                                            // quad_perm [1,0,3,2]
+}
+static __device__ __forceinline__ int lm_red_slot(int lane) {
+    const int m = ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1);                  // which x the lane ended up with
+    if ((lane & 1) || (m == 3 && (lane & 8))) return -1;                      // duplicates
+    const int ui = m == 3 ? 3 : m + 4 * ((lane >> 3) & 1);
+    return ui + 7 * (lane >> 4);
+}
+
+// The points a thread evaluates stay the same through the whole refine: the first LM_CACHED of them live in registers.
+#define LM_CACHED 4
+struct LmPoints { float X[LM_CACHED], Y[LM_CACHED], Z[LM_CACHED], u[LM_CACHED], v[LM_CACHED]; bool in[LM_CACHED]; };
+
+static __device__ __forceinline__ void lm_point(double X, double Y, double Z, double cu, double cv, const double* R, const double* dRdr,
+                                                double t0, double t1, double t2, double fx, double fy, double cx, double cy, double (&acc)[28]) {
+    double x = R[0] * X + R[1] * Y + R[2] * Z + t0;
+    double y = R[3] * X + R[4] * Y + R[5] * Z + t1;
+    double z = R[6] * X + R[7] * Y + R[8] * Z + t2;
+    z = z ? 1. / z : 1;
+    x *= z; y *= z;
+    double ex = x * fx + cx - cu, ey = y * fy + cy - cv;
+    acc[27] += ex * ex + ey * ey;
+    double jx[6], jy[6];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double dx0 = X * dRdr[9 * j + 0] + Y * dRdr[9 * j + 1] + Z * dRdr[9 * j + 2];
+        double dy0 = X * dRdr[9 * j + 3] + Y * dRdr[9 * j + 4] + Z * dRdr[9 * j + 5];
+        double dz0 = X * dRdr[9 * j + 6] + Y * dRdr[9 * j + 7] + Z * dRdr[9 * j + 8];
+        jx[j] = fx * (z * (dx0 - x * dz0));
+        jy[j] = fy * (z * (dy0 - y * dz0));
+    }
+    jx[3] = fx * z; jx[4] = 0; jx[5] = fx * (-x * z);
+    jy[3] = 0; jy[4] = fy * z; jy[5] = fy * (-y * z);
+    int q = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = a; b < 6; b++) acc[q++] += jx[a] * jx[b] + jy[a] * jy[b];
+#pragma unroll
+    for (int a = 0; a < 6; a++) acc[21 + a] += jx[a] * ex + jy[a] * ey;
+}
+
+// one evaluation of residuals and Jacobians over the inliers; totals land in sh.red[0][*]
+static __device__ void lm_eval(const DevBuffers& d, const SeqState& s, size_t o, int n, const LmPoints& pts, LmShared& sh) {
+    if (threadIdx.x == 0) rodrigues_to_matrix(sh.param, sh.R, sh.dRdr);
     __syncthreads();
     const double fx = s.K[0], fy = s.K[4], cx = s.K[2], cy = s.K[5];
     double acc[28];
+#pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = 0;
     const double* R = sh.R; const double* dRdr = sh.dRdr;
     const double t0 = sh.param[3], t1 = sh.param[4], t2 = sh.param[5];
-    for (int i = threadIdx.x; i < n; i += PF_THREADS) {
+#pragma unroll
+    for (int k = 0; k < LM_CACHED; k++)
+        if (pts.in[k]) lm_point(pts.X[k], pts.Y[k], pts.Z[k], pts.u[k], pts.v[k], R, dRdr, t0, t1, t2, fx, fy, cx, cy, acc);
+    for (int i = threadIdx.x + LM_CACHED * PF_THREADS; i < n; i += PF_THREADS) {        // more tracks than the registers hold
         if (!d.inlier[o + i]) continue;
-        double X = d.world[3 * (o + i)], Y = d.world[3 * (o + i) + 1], Z = d.world[3 * (o + i) + 2];
-        float2 c = d.tl1[o + i];
-        double x = R[0] * X + R[1] * Y + R[2] * Z + t0;
-        double y = R[3] * X + R[4] * Y + R[5] * Z + t1;
-        double z = R[6] * X + R[7] * Y + R[8] * Z + t2;
-        z = z ? 1. / z : 1;
-        x *= z; y *= z;
-        double ex = x * fx + cx - (double)c.x, ey = y * fy + cy - (double)c.y;
-        acc[27] += ex * ex + ey * ey;
-        if (with_J) {
-            double jx[6], jy[6];
-            for (int j = 0; j < 3; j++) {
-                double dx0 = X * dRdr[9 * j + 0] + Y * dRdr[9 * j + 1] + Z * dRdr[9 * j + 2];
-                double dy0 = X * dRdr[9 * j + 3] + Y * dRdr[9 * j + 4] + Z * dRdr[9 * j + 5];
-                double dz0 = X * dRdr[9 * j + 6] + Y * dRdr[9 * j + 7] + Z * dRdr[9 * j + 8];
-                jx[j] = fx * (z * (dx0 - x * dz0));
-                jy[j] = fy * (z * (dy0 - y * dz0));
-            }
-            jx[3] = fx * z; jx[4] = 0; jx[5] = fx * (-x * z);
-            jy[3] = 0; jy[4] = fy * z; jy[5] = fy * (-y * z);
-            int q = 0;
-            for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) acc[q++] += jx[a] * jx[b] + jy[a] * jy[b];
-            for (int a = 0; a < 6; a++) acc[21 + a] += jx[a] * ex + jy[a] * ey;
-        }
+        const float2 c = d.tl1[o + i];
+        lm_point(d.world[3 * (o + i)], d.world[3 * (o + i) + 1], d.world[3 * (o + i) + 2], c.x, c.y, R, dRdr, t0, t1, t2, fx, fy, cx, cy, acc);
     }
-    // block reduction: wave level with DPP row steps on the two 32-bit halves of each double (no LDS shuffles), then LDS
-    // across the 4 waves.  A residual-only evaluation needs just the error norm (slot 27).
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int k0 = with_J ? 0 : 27;
-    for (int k = k0; k < 28; k++) {
-        double v = acc[k];
-        v += dpp_f64(v, 0xB1); v += dpp_f64(v, 0x4E); v += dpp_f64(v, 0x141); v += dpp_f64(v, 0x140);   // sum of the 16-lane row in every lane
-        // rows -> wave: lanes 0, 16, 32, 48 hold the row sums
-        double r = v + __shfl(v, (lane + 16) & 63) ;
-        r = r + __shfl(r, (lane + 32) & 63);
-        if (lane == 0) sh.red[wv][k] = r;
-    }
+    const double tot = lm_wave_sums28(acc, lane);
+    const int slot = lm_red_slot(lane);
+    if (slot >= 0) sh.red[wv][slot] = tot;
     __syncthreads();
-    if (threadIdx.x >= k0 && threadIdx.x < 28) {
+    if (threadIdx.x < 28) {
         double t = sh.red[0][threadIdx.x];
 #pragma unroll
         for (int w = 1; w < PF_WAVES; w++) t += sh.red[w][threadIdx.x];
@@ -977,6 +1025,16 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
     }
     __syncthreads();
     // ---- Levenberg–Marquardt refine on the inliers (solvePnP ITERATIVE, useExtrinsicGuess; CvLevMarq state machine)
+    LmPoints pts;
+#pragma unroll
+    for (int k = 0; k < LM_CACHED; k++) {
+        const int i = threadIdx.x + k * PF_THREADS;
+        pts.in[k] = i < n && d.inlier[o + i];
+        const int ii = i < n ? i : 0;
+        const float2 c = d.tl1[o + ii];
+        pts.X[k] = d.world[3 * (o + ii)]; pts.Y[k] = d.world[3 * (o + ii) + 1]; pts.Z[k] = d.world[3 * (o + ii) + 2];
+        pts.u[k] = c.x; pts.v[k] = c.y;
+    }
     if (threadIdx.x == 0) {
         double rv[3];
         rodrigues_to_vector(bestRt, rv);
@@ -992,7 +1050,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
     for (int guard = 0; guard < 1000; guard++) {
         const int mode = sh.mode;
         if (mode == 2) break;
-        lm_eval(d, s, o, n, true, sh);
+        lm_eval(d, s, o, n, pts, sh);
         if (threadIdx.x == 0) {
             bool take_J = false;
             if (mode == 1) {                               // CALC_J at the start point
