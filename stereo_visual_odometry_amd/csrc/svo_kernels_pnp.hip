@@ -934,10 +934,9 @@ static __device__ __forceinline__ void lm_point(double X, double Y, double Z, do
     for (int a = 0; a < 6; a++) acc[21 + a] += jx[a] * ex + jy[a] * ey;
 }
 
-// one evaluation of residuals and Jacobians over the inliers; totals land in sh.red[0][*]
+// one evaluation of residuals and Jacobians over the inliers at sh.R / sh.dRdr / sh.param[3..5]; totals land in sh.red[0][*],
+// visible to wave 0 on return (the caller's barrier publishes what thread 0 does with them)
 static __device__ void lm_eval(const DevBuffers& d, const SeqState& s, size_t o, int n, const LmPoints& pts, LmShared& sh) {
-    if (threadIdx.x == 0) rodrigues_to_matrix(sh.param, sh.R, sh.dRdr);
-    __syncthreads();
     const double fx = s.K[0], fy = s.K[4], cx = s.K[2], cy = s.K[5];
     double acc[28];
 #pragma unroll
@@ -957,13 +956,13 @@ static __device__ void lm_eval(const DevBuffers& d, const SeqState& s, size_t o,
     const int slot = lm_red_slot(lane);
     if (slot >= 0) sh.red[wv][slot] = tot;
     __syncthreads();
-    if (threadIdx.x < 28) {
+    if (threadIdx.x < 28) {                                            // wave 0 alone goes on: its thread 0 runs the state machine
         double t = sh.red[0][threadIdx.x];
 #pragma unroll
         for (int w = 1; w < PF_WAVES; w++) t += sh.red[w][threadIdx.x];
         sh.red[0][threadIdx.x] = t;
     }
-    __syncthreads();
+    if (wv == 0) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 }
 
 static __device__ void lm_step(LmShared& sh) {
@@ -973,6 +972,7 @@ static __device__ void lm_step(LmShared& sh) {
     for (int i = 0; i < 6; i++) A[7 * i] *= 1. + lambda;
     chol_solve6(A, sh.JtErr, x);
     for (int i = 0; i < 6; i++) sh.param[i] = sh.prev[i] - x[i];
+    rodrigues_to_matrix(sh.param, sh.R, sh.dRdr);                       // for the evaluation of this trial point
 }
 
 
@@ -1041,6 +1041,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
         sh.param[0] = rv[0]; sh.param[1] = rv[1]; sh.param[2] = rv[2];
         sh.param[3] = bestRt[9]; sh.param[4] = bestRt[10]; sh.param[5] = bestRt[11];
         sh.lambdaLg10 = -3; sh.iters = 0; sh.state = 0; sh.mode = direct ? 2 : 1; sh.prevErrNorm = 0; sh.lambda_tab = d.lm_lambda;
+        rodrigues_to_matrix(sh.param, sh.R, sh.dRdr);
     }
     __syncthreads();
     // CvLevMarq's state machine (CALC_J -> step -> CHECK_ERR -> accept / raise lambda), with one change of SCHEDULE only: every

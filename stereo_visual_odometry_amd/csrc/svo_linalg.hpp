@@ -281,7 +281,9 @@ __device__ inline void rodrigues_to_matrix(const double r[3], double R[9], doubl
         if (J) { for (int i = 0; i < 27; i++) J[i] = 0; J[5] = J[15] = J[19] = -1; J[7] = J[11] = J[21] = 1; }
         return;
     }
-    double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = 1. / theta;
+    double c, s;
+    sincos(theta, &s, &c);                                             // one argument reduction for both
+    double c1 = 1. - c, itheta = 1. / theta;
     double rx = r[0] * itheta, ry = r[1] * itheta, rz = r[2] * itheta;
     double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
     double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
