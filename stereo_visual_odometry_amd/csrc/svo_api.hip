@@ -142,6 +142,7 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     if (d.CN == 3) ALLOC(d.fastimg, B * 3 * (size_t)width * (size_t)height + 256);
     for (int k = 0; k < 2; k++) { ALLOC(d.feat_xy[k], B * CAP); ALLOC(d.feat_age[k], B * CAP); ALLOC(d.feat_str[k], B * CAP); }
     ALLOC(d.bucket_keys, B * (size_t)d.NB);
+    ALLOC(d.bucket_rowcnt, B * (size_t)cfg.buckets_along_height); ALLOC(d.emit_ticket, B);
     if (cfg.features_per_bucket > 1) {
         d.KPCAP = d.CAP + ((width + 1) / 2) * ((height + 1) / 2);       // strict 3x3 NMS: at most one keypoint per 2x2 block
         const size_t KC = (size_t)d.KPCAP, SL = (size_t)d.NB * cfg.features_per_bucket;
@@ -268,7 +269,7 @@ static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_e
     launch_ingest(d, dp, stride, s);
     launch_pyramid(d, s);
     if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
-    launch_detect(d, 0, -1, s, true);                                // k_frame_begin cleared the keys of the first pass
+    launch_detect(d, 0, -1, s);
     launch_detect(d, 1, -1, s);
     if (with_events) HIPCHK(hipEventRecord(c->ev_lk0[slot], s));
     launch_lk_chain(d, gn, s);
@@ -685,7 +686,7 @@ extern "C" int svo_append_features_from_image(int device, const svo_config* cfg_
     }
     rc = upload_image(c, 0, 0, img, stride); if (rc != SVO_OK) return rc;
     SeqState hs; memset(&hs, 0, sizeof(hs));
-    hs.frame_id = 1; hs.active = 1; hs.slot_img_t0 = 0; hs.slot_pyr_t0 = 0; hs.slot_t1 = 1; hs.n_feat = n; hs.feat_buf = 0;
+    hs.frame_id = 1; hs.active = 1; hs.slot_img_t0 = 0; hs.slot_pyr_t0 = 0; hs.slot_t1 = 1; hs.n_feat = n; hs.n_old = n; hs.feat_buf = 0;
     rc = set_state(c, hs); if (rc != SVO_OK) return rc;
     launch_detect(c->d, 0, fast_threshold, c->stream);
     HIPCHK(hipGetLastError());

@@ -58,6 +58,8 @@ struct DevBuffers {
                                                // the single-channel 'image' cv::FAST sees in a BGR Mat
     float2* feat_xy[2]; int* feat_age[2]; int* feat_str[2];   // [B][CAP] each, double-buffered
     unsigned long long* bucket_keys;           // [B][NB]
+    int* bucket_rowcnt;                        // [B][buckets_along_height] occupied buckets per grid row (counted at first fill)
+    int* emit_ticket;                          // [B] blocks of k_bucket_emit that have finished; keys, row counts and tickets are all zero between passes
     // features_per_bucket > 1 only (the general Bucket::add_feature walk; the default capacity 1 is an argmax and needs none of it):
     int KPCAP;                                 // candidate capacity per sequence = CAP (existing tracks) + keypoints one FAST pass can return
     uint8_t* score;                            // [B][W*H] NMS-surviving FAST scores of the pass
@@ -99,7 +101,7 @@ __host__ __device__ inline int pnp_first_chunk(const DevBuffers& d) { const int 
 void launch_frame_begin(const DevBuffers& d, hipStream_t s);
 void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs /* [2][B] device array */, int stride_bytes, hipStream_t s);
 void launch_pyramid(const DevBuffers& d, hipStream_t s);
-void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s, bool keys_cleared = false);   // pass 0: FAST_THRESHOLD, pass 1: /4 if needed; th_override >= 0 replaces it
+void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s);   // pass 0: FAST_THRESHOLD, pass 1: /4 if needed; th_override >= 0 replaces it
 void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t s);      // grid_n = max features that can enter LK
 void launch_compact(const DevBuffers& d, hipStream_t s);
 void launch_triangulate(const DevBuffers& d, hipStream_t s);

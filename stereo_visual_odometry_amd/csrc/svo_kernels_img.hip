@@ -16,15 +16,11 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // pyramid cache in circularMatching (vo.cpp:179-181 vs 231-232: the cache is NOT refreshed when
 // there were no points to match — the "stale pyramid" quirk).
 // ------------------------------------------------------------------------------------------------
-// Grid (blocks over the bucket grid, sequences): besides the per-frame reset (one thread per sequence) the kernel clears the
-// bucket keys for the first detection pass, which saves that pass a launch of its own (frame_id is not written here, so every
-// block can derive `active` itself).
+// One thread per sequence.  (The bucket keys need no clearing here: every detection pass leaves them zero, see k_bucket_emit.)
 __global__ void k_frame_begin(DevBuffers d) {
-    const int seq = blockIdx.y;
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= d.B) return;
     SeqState& s = d.st[seq];
-    if (s.frame_id > 0)
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.NB; i += gridDim.x * blockDim.x) d.bucket_keys[(size_t)seq * d.NB + i] = 0ull;
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
     s.n_old = s.n_feat;
     s.active = s.frame_id > 0;
     int t1 = 0;
@@ -58,7 +54,7 @@ __global__ void k_frame_end(DevBuffers d, int ring_slot) {
 }
 
 void launch_frame_begin(const DevBuffers& d, hipStream_t st) {
-    hipLaunchKernelGGL(k_frame_begin, dim3((d.NB + 255) / 256, d.B), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_frame_begin, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
 }
 void launch_frame_end(const DevBuffers& d, int ring_slot, hipStream_t st) {
     hipLaunchKernelGGL(k_frame_end, dim3((d.B + 63) / 64), dim3(64), 0, st, d, ring_slot);
@@ -236,6 +232,13 @@ __device__ __forceinline__ unsigned long long make_bucket_key(int score, unsigne
     return ((unsigned long long)s << 48) | ((unsigned long long)(0xFFFFFFFFu - order) << 16) | (unsigned long long)(strength & 0xFFFF);
 }
 
+// Bucket::add_feature for capacity 1 as one 64-bit atomicMax; the first candidate of a bucket also counts it into its grid row,
+// which lets k_bucket_emit place a row's winners without scanning the rows before it.
+__device__ __forceinline__ void bucket_offer(const DevBuffers& d, int seq, int bh, int bw, unsigned long long key) {
+    const unsigned long long old = atomicMax(&d.bucket_keys[(size_t)seq * d.NB + bh * d.cfg.buckets_along_width + bw], key);
+    if (old == 0ull) atomicAdd(&d.bucket_rowcnt[(size_t)seq * d.cfg.buckets_along_height + bh], 1);
+}
+
 // MODE 0: frame pipeline, survivors go straight to the bucket keys (features_per_bucket == 1).  MODE 1: one image -> score map
 // (stage API).  MODE 2: frame pipeline -> per-sequence score map (features_per_bucket > 1: the general walk needs the keypoint list).
 template <int MODE>
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* img_single, int w_s
                 if (bh >= d.cfg.bucket_start_row && bh < d.cfg.buckets_along_height && bw < d.cfg.buckets_along_width && 0 < d.cfg.age_threshold) {
                     int score = 0 + (s - d.cfg.fast_threshold) / 20;                       // feature_set.cpp:16-18
                     unsigned order = (unsigned)d.st[seq].n_old + (unsigned)(gy * W + gx);     // raster rank keeps cv::FAST's output order
-                    atomicMax(&d.bucket_keys[(size_t)seq * d.NB + bh * d.cfg.buckets_along_width + bw], make_bucket_key(score, order, s));
+                    bucket_offer(d, seq, bh, bw, make_bucket_key(score, order, s));
                 }
             }
         } else {
@@ -374,88 +377,103 @@ void launch_score_compact(const uint8_t* score_dev, int w, int h, int cap, int* 
 // key = (score, ~input_index, strength).  Input order = existing tracks first, then the new FAST
 // hits in raster order (feature_set.cpp:83-87).  Emission is bucket-raster order (:132-146).
 // ------------------------------------------------------------------------------------------------
-__global__ void k_bucket_clear(DevBuffers d, int pass) {
-    const int seq = blockIdx.y;
-    SeqState& s = d.st[seq];
-    if (pass == 0 ? !s.active : !s.do_second) return;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.NB; i += gridDim.x * blockDim.x)
-        d.bucket_keys[(size_t)seq * d.NB + i] = 0ull;
-    if (blockIdx.x == 0 && threadIdx.x == 0) s.n_old = s.n_feat;
-}
-
-__global__ void k_bucket_offer_old(DevBuffers d, int pass) {
-    const int seq = blockIdx.y;
-    const SeqState& s = d.st[seq];
-    if (pass == 0 ? !s.active : !s.do_second) return;
-    const int n = s.n_feat, fb = s.feat_buf;
+// the tracks the feature set already holds, offered to the grid (feature_set.cpp:20-53, 122-124) — a device function: the first
+// pass launches it as a kernel, the second pass's offer is made by the last block of the first pass's emit
+static __device__ __forceinline__ void offer_tracks(const DevBuffers& d, int seq, int fb, int n, int first, int step) {
     const float2* xy = d.feat_xy[fb] + (size_t)seq * d.CAP;
     const int* age = d.feat_age[fb] + (size_t)seq * d.CAP;
     const int* str = d.feat_str[fb] + (size_t)seq * d.CAP;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = first; i < n; i += step) {
         float2 p = xy[i];
         int a = age[i], st = str[i];
         int bh = (int)(p.y / (float)d.bucket_h), bw = (int)(p.x / (float)d.bucket_w);   // feature_set.cpp:122-123
         if (p.x < 0.f || p.y < 0.f || bh < d.cfg.bucket_start_row || bh >= d.cfg.buckets_along_height || bw >= d.cfg.buckets_along_width) continue;
         if (a >= d.cfg.age_threshold) continue;                                           // feature_set.cpp:26
         int score = a + (st - d.cfg.fast_threshold) / 20;
-        atomicMax(&d.bucket_keys[(size_t)seq * d.NB + bh * d.cfg.buckets_along_width + bw], make_bucket_key(score, (unsigned)i, st));
+        bucket_offer(d, seq, bh, bw, make_bucket_key(score, (unsigned)i, st));
     }
 }
+__global__ void k_bucket_offer_old(DevBuffers d) {                       // first pass only
+    const int seq = blockIdx.y;
+    const SeqState& s = d.st[seq];
+    if (!s.active) return;
+    offer_tracks(d, seq, s.feat_buf, s.n_feat, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
 
-// one block per sequence: scan the grid in raster order, emit winners.  1024 threads: the serial part of a thread is 15 keys
-// (it was 58 with 256 threads, 50 us at one sequence), which is what bounds the kernel when a single stream runs alone.
-#define SCAN_THREADS 256
-#define SCAN_WAVES (SCAN_THREADS / 64)
-#define EMIT_THREADS 1024
+// Emit the winners in bucket-raster order (feature_set.cpp:132-146): one block per (grid row, sequence).  The rows' occupancy
+// counts (bucket_offer) give a block its first output position; inside the row a ballot scan orders the winners.  Each block
+// zeroes the keys it has read and the LAST block of a sequence (ticket) zeroes the row counts and publishes the new feature set,
+// so keys, counts and tickets are all zero again when the next pass or frame starts — no clearing launch anywhere.  If the first
+// pass kept too few features (vo.cpp:327) that last block also offers the new set to the grid for the second pass.
+#define EMIT_THREADS 256
 #define EMIT_WAVES (EMIT_THREADS / 64)
 __global__ __launch_bounds__(EMIT_THREADS) void k_bucket_emit(DevBuffers d, int pass) {
-    const int seq = blockIdx.x;
+    const int seq = blockIdx.y, row = blockIdx.x;
     SeqState& s = d.st[seq];
     if (pass == 0 ? !s.active : !s.do_second) return;
-    __shared__ int wave_tot[EMIT_WAVES];
-    __shared__ int s_total;
-    const int fb = s.feat_buf, nb = d.NB, n_old = s.n_old, W = d.geom.W;
-    const unsigned long long* keys = d.bucket_keys + (size_t)seq * nb;
+    __shared__ int sh_before[EMIT_WAVES], sh_all[EMIT_WAVES], sh_cnt[EMIT_WAVES], sh_last;
+    const int fb = s.feat_buf, n_old = s.n_old, W = d.geom.W;
+    const int baw = d.cfg.buckets_along_width, bah = d.cfg.buckets_along_height;
+    unsigned long long* keys = d.bucket_keys + (size_t)seq * d.NB + (size_t)row * baw;
+    int* rowcnt = d.bucket_rowcnt + (size_t)seq * bah;
     const float2* oxy = d.feat_xy[fb] + (size_t)seq * d.CAP;
     const int* oage = d.feat_age[fb] + (size_t)seq * d.CAP;
     const int* ostr = d.feat_str[fb] + (size_t)seq * d.CAP;
     float2* nxy = d.feat_xy[fb ^ 1] + (size_t)seq * d.CAP;
     int* nage = d.feat_age[fb ^ 1] + (size_t)seq * d.CAP;
     int* nstr = d.feat_str[fb ^ 1] + (size_t)seq * d.CAP;
-    const int chunk = (nb + EMIT_THREADS - 1) / EMIT_THREADS;
-    const int b0 = threadIdx.x * chunk < nb ? threadIdx.x * chunk : nb, b1 = (b0 + chunk < nb) ? b0 + chunk : nb;
-    int cnt = 0;
-    for (int b = b0; b < b1; b++) cnt += keys[b] != 0ull;
-    // block exclusive scan of cnt
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int incl = cnt;
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    if (lane == 63) wave_tot[wv] = incl;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // winners in the rows before this one, and in all rows
+    int before = 0, all = 0;
+    for (int r = threadIdx.x; r < bah; r += EMIT_THREADS) { const int c = rowcnt[r]; all += c; if (r < row) before += c; }
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); all += __shfl_xor(all, o); }
+    if (lane == 0) { sh_before[wv] = before; sh_all[wv] = all; }
     __syncthreads();
-    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < EMIT_WAVES; i++) { int t = wave_tot[i]; wave_tot[i] = acc; acc += t; } s_total = acc; }
-    __syncthreads();
-    int pos = wave_tot[wv] + incl - cnt;
-    for (int b = b0; b < b1; b++) {
-        unsigned long long k = keys[b];
-        if (k == 0ull) continue;
-        unsigned order = 0xFFFFFFFFu - (unsigned)((k >> 16) & 0xFFFFFFFFull);
-        if (pos < d.CAP) {
+    before = 0; all = 0;
+    for (int w = 0; w < EMIT_WAVES; w++) { before += sh_before[w]; all += sh_all[w]; }
+    int run = before;
+    for (int b0 = 0; b0 < baw; b0 += EMIT_THREADS) {
+        const int bw = b0 + threadIdx.x;
+        unsigned long long k = 0ull;
+        if (bw < baw) { k = keys[bw]; if (k != 0ull) keys[bw] = 0ull; }
+        const unsigned long long m = __ballot(k != 0ull);
+        __syncthreads();                                              // sh_cnt of the previous chunk has been read
+        if (lane == 0) sh_cnt[wv] = __popcll(m);
+        __syncthreads();
+        int pos = run + __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wv; w++) pos += sh_cnt[w];
+        for (int w = 0; w < EMIT_WAVES; w++) run += sh_cnt[w];
+        if (k != 0ull && pos < d.CAP) {
+            const unsigned order = 0xFFFFFFFFu - (unsigned)((k >> 16) & 0xFFFFFFFFull);
             if (order < (unsigned)n_old) { nxy[pos] = oxy[order]; nage[pos] = oage[order]; nstr[pos] = ostr[order]; }
             else {
-                unsigned pixi = order - (unsigned)n_old;
-                int y = (int)(pixi / (unsigned)W), x = (int)(pixi - (unsigned)y * (unsigned)W);
+                const unsigned pixi = order - (unsigned)n_old;
+                const int y = (int)(pixi / (unsigned)W), x = (int)(pixi - (unsigned)y * (unsigned)W);
                 nxy[pos] = make_float2((float)x, (float)y); nage[pos] = 0; nstr[pos] = (int)(k & 0xFFFFull);
             }
         }
-        pos++;
     }
+    // ---- the last block of the sequence to get here publishes the result
+    __threadfence();
     __syncthreads();
+    if (threadIdx.x == 0) sh_last = atomicAdd(&d.emit_ticket[seq], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!sh_last) return;
+    __threadfence();
+    const int total = all < d.CAP ? all : d.CAP;
+    const bool second = pass == 0 && total < d.cfg.pre_matching_feature_threshold;               // vo.cpp:327
+    for (int r = threadIdx.x; r < bah; r += EMIT_THREADS) rowcnt[r] = 0;
     if (threadIdx.x == 0) {
-        int total = s_total < d.CAP ? s_total : d.CAP;
+        d.emit_ticket[seq] = 0;
         s.n_feat = total; s.feat_buf = fb ^ 1;
         s.stats.n_after_detect = total;
-        if (pass == 0) s.do_second = total < d.cfg.pre_matching_feature_threshold;   // vo.cpp:327
+        if (pass == 0) { s.do_second = second; if (second) s.n_old = total; }
         else s.stats.second_pass = 1;
+    }
+    if (second) {                                                     // block-uniform
+        __threadfence();
+        __syncthreads();
+        offer_tracks(d, seq, fb ^ 1, total, threadIdx.x, EMIT_THREADS);
     }
 }
 
@@ -539,16 +557,18 @@ __global__ void k_gen_bucket_walk(DevBuffers d, int pass) {
     }
     d.slot_n[(size_t)seq * d.NB + b] = cnt;
 }
-__global__ __launch_bounds__(EMIT_THREADS) void k_gen_bucket_emit(DevBuffers d, int pass) {
+#define GEN_EMIT_THREADS 1024
+#define GEN_EMIT_WAVES (GEN_EMIT_THREADS / 64)
+__global__ __launch_bounds__(GEN_EMIT_THREADS) void k_gen_bucket_emit(DevBuffers d, int pass) {
     const int seq = blockIdx.x;
     SeqState& s = d.st[seq];
     if (!pass_runs(s, pass)) return;
-    __shared__ int wave_tot[EMIT_WAVES];
+    __shared__ int wave_tot[GEN_EMIT_WAVES];
     __shared__ int s_total;
     const int fb = s.feat_buf, nb = d.NB, per = d.cfg.features_per_bucket;
     const int* sn = d.slot_n + (size_t)seq * nb;
     float2* nxy = d.feat_xy[fb ^ 1] + (size_t)seq * d.CAP; int* nage = d.feat_age[fb ^ 1] + (size_t)seq * d.CAP; int* nstr = d.feat_str[fb ^ 1] + (size_t)seq * d.CAP;
-    const int chunk = (nb + EMIT_THREADS - 1) / EMIT_THREADS;
+    const int chunk = (nb + GEN_EMIT_THREADS - 1) / GEN_EMIT_THREADS;
     const int b0 = threadIdx.x * chunk < nb ? threadIdx.x * chunk : nb, b1 = (b0 + chunk < nb) ? b0 + chunk : nb;
     int cnt = 0;
     for (int b = b0; b < b1; b++) cnt += sn[b];
@@ -557,7 +577,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_gen_bucket_emit(DevBuffers d, 
     for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
     if (lane == 63) wave_tot[wv] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < EMIT_WAVES; i++) { int t = wave_tot[i]; wave_tot[i] = acc; acc += t; } s_total = acc; }
+    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < GEN_EMIT_WAVES; i++) { int t = wave_tot[i]; wave_tot[i] = acc; acc += t; } s_total = acc; }
     __syncthreads();
     int pos = wave_tot[wv] + incl - cnt;
     for (int b = b0; b < b1; b++) {
@@ -582,19 +602,18 @@ static void launch_detect_general(const DevBuffers& d, int pass, int th, hipStre
     hipLaunchKernelGGL(k_gen_scan_rows, dim3((d.B + 63) / 64), dim3(64), 0, st, d, pass);
     hipLaunchKernelGGL(k_gen_emit_candidates, dim3(H + 1, d.B), dim3(64), 0, st, d, pass);
     hipLaunchKernelGGL(k_gen_bucket_walk, dim3((d.NB + 255) / 256, d.B), dim3(256), 0, st, d, pass);
-    hipLaunchKernelGGL(k_gen_bucket_emit, dim3(d.B), dim3(EMIT_THREADS), 0, st, d, pass);
+    hipLaunchKernelGGL(k_gen_bucket_emit, dim3(d.B), dim3(GEN_EMIT_THREADS), 0, st, d, pass);
 }
 
-// keys_cleared: the bucket keys of this pass were already cleared (k_frame_begin does it for pass 0 of a pipeline frame)
-void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t st, bool keys_cleared) {
+void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t st) {
     int th = pass == 0 ? d.cfg.fast_threshold : d.cfg.fast_threshold / 4;            // vo.cpp:325 / :329-330
     if (th_override >= 0) th = th_override;
     if (d.cfg.features_per_bucket > 1) { launch_detect_general(d, pass, th, st); return; }
-    if (!keys_cleared) hipLaunchKernelGGL(k_bucket_clear, dim3((d.NB + 255) / 256, d.B), dim3(256), 0, st, d, pass);
-    hipLaunchKernelGGL(k_bucket_offer_old, dim3((d.CAP + 255) / 256, d.B), dim3(256), 0, st, d, pass);
+    // pass 1 finds its tracks already offered (and n_old set) by the last block of pass 0's emit
+    if (pass == 0) hipLaunchKernelGGL(k_bucket_offer_old, dim3((d.CAP + 255) / 256, d.B), dim3(256), 0, st, d);
     dim3 g((d.geom.W + FT_W - 1) / FT_W, (d.geom.H + FT_H - 1) / FT_H, d.B);
     hipLaunchKernelGGL(k_fast<0>, g, dim3(256), 0, st, (const uint8_t*)nullptr, 0, 0, (uint8_t*)nullptr, d, pass, th);
-    hipLaunchKernelGGL(k_bucket_emit, dim3(d.B), dim3(EMIT_THREADS), 0, st, d, pass);
+    hipLaunchKernelGGL(k_bucket_emit, dim3(d.cfg.buckets_along_height, d.B), dim3(EMIT_THREADS), 0, st, d, pass);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -653,6 +672,8 @@ void launch_bucket_general(int img_w, int img_h, int n, const float2* xy, const 
 // ages[i] += 1 (vo.cpp:70-72) and the "too few tracks" gate (vo.cpp:82-84).
 // One 256-thread block per sequence, order-preserving prefix sum.
 // ------------------------------------------------------------------------------------------------
+#define SCAN_THREADS 256
+#define SCAN_WAVES (SCAN_THREADS / 64)
 __global__ __launch_bounds__(SCAN_THREADS) void k_compact(DevBuffers d) {
     const int seq = blockIdx.x;
     SeqState& s = d.st[seq];
