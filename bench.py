@@ -173,6 +173,7 @@ def main():
     for c in range(C):
         v = api.BatchVisualOdometry(W, H, Bc, api.default_config(**over), device=local_rank)
         v.initalize_projection_matricies(Pl, Pr)
+        v.set_stage_timing(True)                 # the roofline needs the LK kernel's own HIP events
         vos.append(v)
 
     total = args.warmup + args.steps

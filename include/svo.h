@@ -133,6 +133,10 @@ int svo_get_last_tracks(svo_context* ctx, int seq, int cap, float* pl0, float* p
  * default: measured slightly slower than the launch list on MI355X): stage events are then not recorded and lk_ms /
  * svo_get_stage_timing fail with SVO_ERR_STATE; frame_ms is always available. */
 int svo_get_last_timing(svo_context* ctx, float* lk_ms, float* frame_ms);
+/* The four stage-boundary events of a frame cost a lone stream ~10 us per frame (measured, one sequence), so they are recorded
+ * only on request: svo_set_stage_timing(ctx, 1), or SVO_STAGE_TIMING=1 in the environment when the context is created.  While
+ * off, lk_ms and svo_get_stage_timing fail with SVO_ERR_STATE; frame_ms is always available. */
+int svo_set_stage_timing(svo_context* ctx, int on);
 /* Per-stage HIP-event milliseconds of the last collected frame (all sequences of the context together), in pipeline order:
  * ms[0] ingest + pyramids (vo.cpp:74-75, 200-201)   ms[1] FAST + bucketing, both passes (vo.cpp:325-332)
  * ms[2] the four LK passes + masks (vo.cpp:203-230, 341-359)   ms[3] compaction + triangulation (vo.cpp:233-238, 360-364, 89-94)

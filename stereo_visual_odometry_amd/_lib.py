@@ -68,7 +68,7 @@ lib.svo_get_stream.argtypes = [C.c_void_p]
 EXPORTS = [
     "svo_last_error", "svo_device_count", "svo_config_default", "svo_create", "svo_destroy", "svo_set_projection",
     "svo_process_batch", "svo_process", "svo_circular_matching", "svo_submit_batch", "svo_collect", "svo_get_features", "svo_get_last_tracks",
-    "svo_get_last_timing", "svo_get_stage_timing", "svo_get_stream", "svo_fast_detect", "svo_fast_score_map", "svo_bucket_filter",
+    "svo_get_last_timing", "svo_set_stage_timing", "svo_get_stage_timing", "svo_get_stream", "svo_fast_detect", "svo_fast_score_map", "svo_bucket_filter",
     "svo_append_features_from_image", "svo_build_pyramid", "svo_lk_track", "svo_circular_match",
     "svo_find_close_points", "svo_stage_cache_clear", "svo_triangulate", "svo_camera_to_world", "svo_inverse_transform",
 ]

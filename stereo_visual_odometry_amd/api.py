@@ -292,6 +292,11 @@ class BatchVisualOdometry:
         self.stats = list(st)
         return ok.astype(bool), T.reshape(self.n_seq, 4, 4)
 
+    def set_stage_timing(self, on=True):
+        """Record the stage-boundary events of every frame from now on (svo_set_stage_timing): last_timing()'s LK time and
+        stage_timing() need them; off by default (they cost a lone stream ~10 us per frame)."""
+        check(lib.svo_set_stage_timing(self._h, int(bool(on))))
+
     def last_timing(self):
         lk, fr = C.c_float(0), C.c_float(0)
         check(lib.svo_get_last_timing(self._h, C.byref(lk), C.byref(fr)))
@@ -333,6 +338,12 @@ class VisualOdometry(BatchVisualOdometry):
             super().__init__(width, height, 1, cfg, device)
             self._created = True
         self._P = None
+        self._timing = None
+
+    def set_stage_timing(self, on=True):
+        self._timing = bool(on)
+        if self._created:
+            super().set_stage_timing(on)
 
     def initalize_projection_matricies(self, leftCameraProjection, rightCameraProjection, seq=-1):
         self._P = (leftCameraProjection, rightCameraProjection)
@@ -350,6 +361,8 @@ class VisualOdometry(BatchVisualOdometry):
             # like the reference, a first frame needs no projection matrices (vo.cpp:47-56 only caches); until
             # initalize_projection_matricies is called they are all-zero, as the reference's empty Mats effectively are
             super().initalize_projection_matricies(*(self._P if self._P is not None else (np.zeros(12, np.float32), np.zeros(12, np.float32))))
+            if self._timing is not None:
+                super().set_stage_timing(self._timing)
         self._check_frame(L, "left"); self._check_frame(R, "right")
         T = np.zeros(16)
         st = SvoFrameStats()

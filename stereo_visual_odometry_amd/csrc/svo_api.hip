@@ -82,6 +82,7 @@ struct svo_context {
     // hipGraph replay of the frame's launch list (one executable graph per results-ring slot: the slot fixes the pointer table,
     // the result record and the copies; re-captured when the stride or the LK grid size changes)
     bool use_graph = false;
+    bool stage_timing = false;                   // record the four stage-boundary events of a frame (svo_set_stage_timing; SVO_STAGE_TIMING=1)
     hipGraphExec_t gexec[SVO_RING] = {};
     int g_stride[SVO_RING] = {}, g_gn[SVO_RING] = {};
     bool staged_slot[SVO_RING] = {};             // the slot's stage events were recorded (launch-list mode only)
@@ -165,14 +166,14 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
         HIPCHK(hipStreamSynchronize(c->stream));                          // h is a stack array
         d.lm_lambda = lam;
     }
-    ALLOC(d.img_ptrs, (size_t)SVO_RING * 2 * B);
 #undef ALLOC
     // the results ring lives in pinned HOST memory that the device can write: k_frame_end stores the B records there directly
     // (180 B per sequence over PCIe) instead of a device buffer plus a copy operation per frame
     HIPCHK(hipHostMalloc((void**)&c->h_results, sizeof(FrameResult) * SVO_RING * B, hipHostMallocMapped));
     memset(c->h_results, 0, sizeof(FrameResult) * SVO_RING * B);
     { void* dv = nullptr; HIPCHK(hipHostGetDevicePointer(&dv, c->h_results, 0)); d.results = (FrameResult*)dv; }
-    HIPCHK(hipHostMalloc((void**)&c->h_ptrs, sizeof(uint8_t*) * SVO_RING * 2 * B));
+    HIPCHK(hipHostMalloc((void**)&c->h_ptrs, sizeof(uint8_t*) * SVO_RING * 2 * B, hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&d.img_ptrs, (void*)c->h_ptrs, 0));   // read in place by k_ingest: no per-frame upload
     for (int i = 0; i < SVO_RING; i++) {
         HIPCHK(hipEventCreate(&c->ev_done[i])); HIPCHK(hipEventCreate(&c->ev_f0[i]));
         HIPCHK(hipEventCreate(&c->ev_lk0[i])); HIPCHK(hipEventCreate(&c->ev_lk1[i]));
@@ -195,6 +196,8 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
         // the default and the graph is the option.
         const char* e = getenv("SVO_GRAPH");
         c->use_graph = e ? atoi(e) != 0 : false;
+        const char* t = getenv("SVO_STAGE_TIMING");
+        c->stage_timing = t ? atoi(t) != 0 : false;
     }
     undo.c = nullptr;
     *out = c;
@@ -262,11 +265,8 @@ static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_e
     DevBuffers& d = c->d;
     const int B = d.B;
     hipStream_t s = c->stream;
-    const uint8_t** hp = c->h_ptrs + (size_t)slot * 2 * B;
-    const uint8_t** dp = d.img_ptrs + (size_t)slot * 2 * B;
-    HIPCHK(hipMemcpyAsync((void*)dp, (const void*)hp, sizeof(uint8_t*) * 2 * B, hipMemcpyHostToDevice, s));
-    launch_frame_begin(d, s);
-    launch_ingest(d, dp, stride, s);
+    const uint8_t** dp = d.img_ptrs + (size_t)slot * 2 * B;         // the slot's pointer table: pinned host memory the kernel reads in place
+    launch_ingest(d, dp, stride, s, true);                            // + the per-frame reset
     launch_pyramid(d, s);
     if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
     launch_detect(d, 0, -1, s);
@@ -317,8 +317,8 @@ static int enqueue_frame(svo_context* c, const uint8_t* const* left_dev, const u
         }
         if (c->use_graph) { HIPCHK(hipGraphLaunch(c->gexec[slot], s)); replayed = true; }
     }
-    if (!replayed) { const int rc = issue_frame(c, slot, stride, gn, true); if (rc != SVO_OK) return rc; }
-    c->staged_slot[slot] = !replayed;
+    if (!replayed) { const int rc = issue_frame(c, slot, stride, gn, c->stage_timing); if (rc != SVO_OK) return rc; }
+    c->staged_slot[slot] = !replayed && c->stage_timing;
     HIPCHK(hipEventRecord(c->ev_done[slot], s));
     HIPCHK(hipGetLastError());
     c->head = (c->head + 1) % SVO_RING; c->inflight++;
@@ -446,8 +446,7 @@ extern "C" int svo_circular_matching(svo_context* c, const uint8_t* left_t1, con
     const uint8_t* l[1] = {left_t1}; const uint8_t* r[1] = {right_t1};
     if ((rc = stage_host_images(c, l, r, stride, lp, rp)) != SVO_OK) return rc;
     const uint8_t** hp = c->h_ptrs; hp[0] = lp[0]; hp[1] = rp[0];
-    HIPCHK(hipMemcpyAsync((void*)c->d.img_ptrs, (const void*)hp, sizeof(uint8_t*) * 2, hipMemcpyHostToDevice, c->stream));
-    launch_ingest(c->d, c->d.img_ptrs, c->d.geom.W * c->d.CN, c->stream);
+    launch_ingest(c->d, c->d.img_ptrs, c->d.geom.W * c->d.CN, c->stream, false);
     launch_pyramid(c->d, c->stream);                                              // vo.cpp:200-201
     launch_lk_chain(c->d, n, c->stream);                                          // vo.cpp:203-230
     HIPCHK(hipGetLastError());
@@ -463,12 +462,18 @@ extern "C" int svo_circular_matching(svo_context* c, const uint8_t* left_t1, con
     return set_state(c, out);
 }
 
+extern "C" int svo_set_stage_timing(svo_context* c, int on) {
+    if (!c) return fail_arg("null context");
+    c->stage_timing = on != 0;
+    return SVO_OK;
+}
+
 extern "C" int svo_get_last_timing(svo_context* c, float* lk_ms, float* frame_ms) {
     if (!c || c->last_slot < 0) return fail_arg("no frame collected yet");
     HIPCHK(hipSetDevice(c->device));
     const int s = c->last_slot;
     if (lk_ms) {
-        if (!c->staged_slot[s]) { g_err = "stage events are not recorded while frames are replayed as a hipGraph (SVO_GRAPH=0)"; return SVO_ERR_STATE; }
+        if (!c->staged_slot[s]) { g_err = "no stage events for this frame: call svo_set_stage_timing(ctx, 1) first (and SVO_GRAPH must be off)"; return SVO_ERR_STATE; }
         HIPCHK(hipEventElapsedTime(lk_ms, c->ev_lk0[s], c->ev_lk1[s]));
     }
     if (frame_ms) HIPCHK(hipEventElapsedTime(frame_ms, c->ev_f0[s], c->ev_done[s]));
@@ -479,7 +484,7 @@ extern "C" int svo_get_stage_timing(svo_context* c, float ms[5]) {
     if (!c || !ms || c->last_slot < 0) return fail_arg("no frame collected yet");
     HIPCHK(hipSetDevice(c->device));
     const int s = c->last_slot;
-    if (!c->staged_slot[s]) { g_err = "stage events are not recorded while frames are replayed as a hipGraph (SVO_GRAPH=0)"; return SVO_ERR_STATE; }
+    if (!c->staged_slot[s]) { g_err = "no stage events for this frame: call svo_set_stage_timing(ctx, 1) first (and SVO_GRAPH must be off)"; return SVO_ERR_STATE; }
     hipEvent_t ev[6] = {c->ev_f0[s], c->ev_pyr[s], c->ev_lk0[s], c->ev_lk1[s], c->ev_tri[s], c->ev_done[s]};
     for (int i = 0; i < 5; i++) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
     return SVO_OK;

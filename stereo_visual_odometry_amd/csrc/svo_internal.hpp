@@ -81,7 +81,7 @@ struct DevBuffers {
     double ransac_log_num;                     // log(max(1 - confidence, DBL_MIN)): the numerator of RANSACUpdateNumIters, computed by the host
     const double* lm_lambda;                   // [33] 10^k, k = -16..16 (the damping factors CvLevMarq can reach), computed on the host
     FrameResult* results;                      // [SVO_RING][B]
-    const uint8_t** img_ptrs;                  // [SVO_RING][2][B] device array of source image pointers
+    const uint8_t** img_ptrs;                  // [SVO_RING][2][B] source image pointers: pinned host memory, read in place
 };
 
 // plane 0 of the pyramid of (sequence, slot, camera); plane k follows at + k * geom.pyr_bytes
@@ -98,8 +98,8 @@ __host__ __device__ inline size_t fastimg_index(const DevBuffers& d, int seq, in
 __host__ __device__ inline int pnp_first_chunk(const DevBuffers& d) { const int c = d.B <= 8 ? 32 : 16; return d.K < c ? d.K : c; }
 
 // ---- launchers (each enqueues on `s`; none synchronises) ----
-void launch_frame_begin(const DevBuffers& d, hipStream_t s);
-void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs /* [2][B] device array */, int stride_bytes, hipStream_t s);
+void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs /* [2][B] device-readable array */, int stride_bytes, hipStream_t s,
+                   bool begin_frame /* also run the per-frame reset of stereo_callback */);
 void launch_pyramid(const DevBuffers& d, hipStream_t s);
 void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s);   // pass 0: FAST_THRESHOLD, pass 1: /4 if needed; th_override >= 0 replaces it
 void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t s);      // grid_n = max features that can enter LK

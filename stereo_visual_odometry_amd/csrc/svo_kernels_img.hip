@@ -16,16 +16,18 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // pyramid cache in circularMatching (vo.cpp:179-181 vs 231-232: the cache is NOT refreshed when
 // there were no points to match — the "stale pyramid" quirk).
 // ------------------------------------------------------------------------------------------------
-// One thread per sequence.  (The bucket keys need no clearing here: every detection pass leaves them zero, see k_bucket_emit.)
-__global__ void k_frame_begin(DevBuffers d) {
-    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seq >= d.B) return;
-    SeqState& s = d.st[seq];
-    s.n_old = s.n_feat;
-    s.active = s.frame_id > 0;
+// The per-frame reset, run by one thread per sequence inside the ingest kernel (begin_frame).  The T1 slot is a function of two
+// fields the reset does not write, so every ingest block derives it for itself.  (The bucket keys need no clearing: every
+// detection pass leaves them zero, see k_bucket_emit.)
+__device__ __forceinline__ int free_slot(const SeqState& s) {
     int t1 = 0;
     for (int c = 0; c < 3; c++) if (c != s.slot_img_t0 && c != s.slot_pyr_t0) { t1 = c; break; }
-    s.slot_t1 = t1;
+    return t1;
+}
+__device__ __forceinline__ void frame_begin(SeqState& s) {
+    s.n_old = s.n_feat;
+    s.active = s.frame_id > 0;
+    s.slot_t1 = free_slot(s);
     s.do_second = 0; s.n_lk = 0; s.n_tracks = 0; s.n_circ = 0; s.n_inliers = 0; s.ok = 0;
     s.pnp_best = -1; s.pnp_iters = 0; s.pnp_good = 0; s.pnp_drawn = 0;
     s.fail_reason = s.active ? 0 : 1;
@@ -53,9 +55,6 @@ __global__ void k_frame_end(DevBuffers d, int ring_slot) {
     r.stats = s.stats;
 }
 
-void launch_frame_begin(const DevBuffers& d, hipStream_t st) {
-    hipLaunchKernelGGL(k_frame_begin, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
-}
 void launch_frame_end(const DevBuffers& d, int ring_slot, hipStream_t st) {
     hipLaunchKernelGGL(k_frame_end, dim3((d.B + 63) / 64), dim3(64), 0, st, d, ring_slot);
 }
@@ -64,13 +63,15 @@ void launch_frame_end(const DevBuffers& d, int ring_slot, hipStream_t st) {
 // ingest: copy the caller's two images into level 0 of the T1 pyramid slot (the deep copies of
 // vo.cpp:74-75 / the level-0 copy of cv::buildOpticalFlowPyramid).  One thread = 4 pixels of a row.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ingest(DevBuffers d, const uint8_t* const* srcs, int stride) {
+__global__ __launch_bounds__(256) void k_ingest(DevBuffers d, const uint8_t* const* srcs, int stride, int begin_frame) {
     const int seq = blockIdx.z, cam = blockIdx.y;
     const int W = d.geom.W, H = d.geom.H;
     const int quads_per_row = (W + 3) >> 2;
     const int total = quads_per_row * H;
     const uint8_t* src = srcs[cam * d.B + seq];
-    uint8_t* dst = d.pyr + pyr_index(d, seq, d.st[seq].slot_t1, cam);
+    const int slot = begin_frame ? free_slot(d.st[seq]) : d.st[seq].slot_t1;
+    if (begin_frame && blockIdx.x == 0 && cam == 0 && threadIdx.x == 0) frame_begin(d.st[seq]);
+    uint8_t* dst = d.pyr + pyr_index(d, seq, slot, cam);
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
         int y = q / quads_per_row, x = (q - y * quads_per_row) << 2;
         const uint8_t* sp = src + (size_t)y * stride + x;
@@ -82,12 +83,13 @@ __global__ __launch_bounds__(256) void k_ingest(DevBuffers d, const uint8_t* con
 
 // Colour form: interleaved BGR rows -> three planes (level 0 of the three per-plane pyramids) and, for the left camera, the
 // W x H byte image made of the first W bytes of every row, which is what cv::FAST scans in a 3-channel Mat.
-__global__ __launch_bounds__(256) void k_ingest_bgr(DevBuffers d, const uint8_t* const* srcs, int stride) {
+__global__ __launch_bounds__(256) void k_ingest_bgr(DevBuffers d, const uint8_t* const* srcs, int stride, int begin_frame) {
     const int seq = blockIdx.z, cam = blockIdx.y;
     const int W = d.geom.W, H = d.geom.H;
     const int total = W * H;
     const uint8_t* src = srcs[cam * d.B + seq];
-    const int slot = d.st[seq].slot_t1;
+    const int slot = begin_frame ? free_slot(d.st[seq]) : d.st[seq].slot_t1;
+    if (begin_frame && blockIdx.x == 0 && cam == 0 && threadIdx.x == 0) frame_begin(d.st[seq]);
     uint8_t* p0 = d.pyr + pyr_index(d, seq, slot, cam);
     uint8_t* fi = d.fastimg + fastimg_index(d, seq, slot);
     const size_t pb = (size_t)d.geom.pyr_bytes;
@@ -99,15 +101,16 @@ __global__ __launch_bounds__(256) void k_ingest_bgr(DevBuffers d, const uint8_t*
     }
 }
 
-void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride, hipStream_t st) {
+// begin_frame: the kernel also performs the per-frame reset of stereo_callback (frame pipeline); the stage entry points pass false
+void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride, hipStream_t st, bool begin_frame) {
     if (d.CN == 3) {
         int gx = (d.geom.W * d.geom.H + 255) / 256; if (gx > 2048) gx = 2048;
-        hipLaunchKernelGGL(k_ingest_bgr, dim3(gx, 2, d.B), dim3(256), 0, st, d, left_right_dev_ptrs, stride);
+        hipLaunchKernelGGL(k_ingest_bgr, dim3(gx, 2, d.B), dim3(256), 0, st, d, left_right_dev_ptrs, stride, (int)begin_frame);
         return;
     }
     int total = ((d.geom.W + 3) >> 2) * d.geom.H;
     int gx = (total + 255) / 256; if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(k_ingest, dim3(gx, 2, d.B), dim3(256), 0, st, d, left_right_dev_ptrs, stride);
+    hipLaunchKernelGGL(k_ingest, dim3(gx, 2, d.B), dim3(256), 0, st, d, left_right_dev_ptrs, stride, (int)begin_frame);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -239,6 +242,22 @@ __device__ __forceinline__ void bucket_offer(const DevBuffers& d, int seq, int b
     if (old == 0ull) atomicAdd(&d.bucket_rowcnt[(size_t)seq * d.cfg.buckets_along_height + bh], 1);
 }
 
+// the tracks the feature set already holds, offered to the grid (feature_set.cpp:20-53, 122-124) — the first pass's k_fast blocks
+// share them out before they scan their tiles, the second pass's offer is made by the last block of the first pass's emit
+static __device__ __forceinline__ void offer_tracks(const DevBuffers& d, int seq, int fb, int n, int first, int step) {
+    const float2* xy = d.feat_xy[fb] + (size_t)seq * d.CAP;
+    const int* age = d.feat_age[fb] + (size_t)seq * d.CAP;
+    const int* str = d.feat_str[fb] + (size_t)seq * d.CAP;
+    for (int i = first; i < n; i += step) {
+        float2 p = xy[i];
+        int a = age[i], st = str[i];
+        int bh = (int)(p.y / (float)d.bucket_h), bw = (int)(p.x / (float)d.bucket_w);   // feature_set.cpp:122-123
+        if (p.x < 0.f || p.y < 0.f || bh < d.cfg.bucket_start_row || bh >= d.cfg.buckets_along_height || bw >= d.cfg.buckets_along_width) continue;
+        if (a >= d.cfg.age_threshold) continue;                                           // feature_set.cpp:26
+        int score = a + (st - d.cfg.fast_threshold) / 20;
+        bucket_offer(d, seq, bh, bw, make_bucket_key(score, (unsigned)i, st));
+    }
+}
 // MODE 0: frame pipeline, survivors go straight to the bucket keys (features_per_bucket == 1).  MODE 1: one image -> score map
 // (stage API).  MODE 2: frame pipeline -> per-sequence score map (features_per_bucket > 1: the general walk needs the keypoint list).
 template <int MODE>
@@ -258,6 +277,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* img_single, int w_s
         // FAST runs on the PREVIOUS left image (vo.cpp:325); for a BGR context on the byte image cv::FAST really scans
         img = d.CN == 3 ? d.fastimg + fastimg_index(d, seq, s.slot_img_t0) : d.pyr + pyr_index(d, seq, s.slot_img_t0, 0);
         if (MODE == 2) score_out = d.score + (size_t)seq * W * H;
+        if (TO_BUCKETS && pass == 0)                                 // the existing tracks enter the grid here (no launch of their own)
+            offer_tracks(d, seq, s.feat_buf, s.n_feat, (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x, gridDim.x * gridDim.y * 256);
     } else { W = w_single; H = h_single; img = img_single; }
     if (threshold < 0) threshold = 0;
     if (threshold > 255) threshold = 255;
@@ -377,29 +398,6 @@ void launch_score_compact(const uint8_t* score_dev, int w, int h, int cap, int* 
 // key = (score, ~input_index, strength).  Input order = existing tracks first, then the new FAST
 // hits in raster order (feature_set.cpp:83-87).  Emission is bucket-raster order (:132-146).
 // ------------------------------------------------------------------------------------------------
-// the tracks the feature set already holds, offered to the grid (feature_set.cpp:20-53, 122-124) — a device function: the first
-// pass launches it as a kernel, the second pass's offer is made by the last block of the first pass's emit
-static __device__ __forceinline__ void offer_tracks(const DevBuffers& d, int seq, int fb, int n, int first, int step) {
-    const float2* xy = d.feat_xy[fb] + (size_t)seq * d.CAP;
-    const int* age = d.feat_age[fb] + (size_t)seq * d.CAP;
-    const int* str = d.feat_str[fb] + (size_t)seq * d.CAP;
-    for (int i = first; i < n; i += step) {
-        float2 p = xy[i];
-        int a = age[i], st = str[i];
-        int bh = (int)(p.y / (float)d.bucket_h), bw = (int)(p.x / (float)d.bucket_w);   // feature_set.cpp:122-123
-        if (p.x < 0.f || p.y < 0.f || bh < d.cfg.bucket_start_row || bh >= d.cfg.buckets_along_height || bw >= d.cfg.buckets_along_width) continue;
-        if (a >= d.cfg.age_threshold) continue;                                           // feature_set.cpp:26
-        int score = a + (st - d.cfg.fast_threshold) / 20;
-        bucket_offer(d, seq, bh, bw, make_bucket_key(score, (unsigned)i, st));
-    }
-}
-__global__ void k_bucket_offer_old(DevBuffers d) {                       // first pass only
-    const int seq = blockIdx.y;
-    const SeqState& s = d.st[seq];
-    if (!s.active) return;
-    offer_tracks(d, seq, s.feat_buf, s.n_feat, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
-}
-
 // Emit the winners in bucket-raster order (feature_set.cpp:132-146): one block per (grid row, sequence).  The rows' occupancy
 // counts (bucket_offer) give a block its first output position; inside the row a ballot scan orders the winners.  Each block
 // zeroes the keys it has read and the LAST block of a sequence (ticket) zeroes the row counts and publishes the new feature set,
@@ -609,8 +607,7 @@ void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s
     int th = pass == 0 ? d.cfg.fast_threshold : d.cfg.fast_threshold / 4;            // vo.cpp:325 / :329-330
     if (th_override >= 0) th = th_override;
     if (d.cfg.features_per_bucket > 1) { launch_detect_general(d, pass, th, st); return; }
-    // pass 1 finds its tracks already offered (and n_old set) by the last block of pass 0's emit
-    if (pass == 0) hipLaunchKernelGGL(k_bucket_offer_old, dim3((d.CAP + 255) / 256, d.B), dim3(256), 0, st, d);
+    // pass 0: k_fast offers the existing tracks itself; pass 1 finds them offered (and n_old set) by the last block of pass 0's emit
     dim3 g((d.geom.W + FT_W - 1) / FT_W, (d.geom.H + FT_H - 1) / FT_H, d.B);
     hipLaunchKernelGGL(k_fast<0>, g, dim3(256), 0, st, (const uint8_t*)nullptr, 0, 0, (uint8_t*)nullptr, d, pass, th);
     hipLaunchKernelGGL(k_bucket_emit, dim3(d.cfg.buckets_along_height, d.B), dim3(EMIT_THREADS), 0, st, d, pass);

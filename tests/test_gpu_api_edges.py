@@ -133,8 +133,13 @@ def test_timing_and_stream_accessors(api, monkeypatch):
     seq, cal = small_seq(n=2)
     vo = api.BatchVisualOdometry(320, 160, 1, api.default_config(max_translation_norm=2.0))
     vo.initalize_projection_matricies(*syn.projection_matrices(cal))
-    for k in range(2):
-        vo.stereo_callback_batch([seq.left[k]], [seq.right[k]])
+    vo.stereo_callback_batch([seq.left[0]], [seq.right[0]])
+    with pytest.raises(api._lib.SvoError):                            # stage events are recorded on request only
+        vo.stage_timing()
+    fr0 = C.c_float(0)
+    assert api.lib.svo_get_last_timing(vo._h, None, C.byref(fr0)) == 0 and fr0.value > 0
+    vo.set_stage_timing(True)
+    vo.stereo_callback_batch([seq.left[1]], [seq.right[1]])
     lk, fr = vo.last_timing()
     assert 0 < lk < fr < 1000
     assert vo.stream()
@@ -154,6 +159,7 @@ def test_graph_replay_equals_the_launch_list(api, monkeypatch):
     for mode in ("1", "0"):
         monkeypatch.setenv("SVO_GRAPH", mode)
         vo = api.VisualOdometry(cfg=api.default_config(max_translation_norm=2.0)); vo.initalize_projection_matricies(*P)
+        vo.set_stage_timing(True)
         res = []
         for k in range(12):
             L, R = seq.left[k], seq.right[k]
