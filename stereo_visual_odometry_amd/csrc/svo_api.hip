@@ -9,6 +9,7 @@
 #include <stddef.h>
 #include <stdlib.h>
 #include <string>
+#include <mutex>
 #include <vector>
 #include <math.h>
 
@@ -27,6 +28,13 @@ extern "C" const char* svo_last_error(void) { return g_err.c_str(); }
     } while (0)
 
 static int fail_arg(const char* msg) { g_err = msg; return SVO_ERR_ARG; }
+
+// The LK kernel of a many-sequence context fills the whole GPU.  When several such contexts share a device (bench.py interleaves
+// two, so that one's latency-bound PnP kernels run under the other's LK), their LK launches are chained through one event per
+// device: two LK grids resident together only halve each other's CUs, and HIP-event durations of either would include the other.
+struct LkGate { std::mutex mu; hipEvent_t ev = nullptr; bool armed = false; int contexts = 0; };
+static LkGate g_lk_gate[SVO_MAX_DEVICES];
+static bool lk_gated(const svo_context* c);
 
 extern "C" int svo_device_count(void) {
     int n = 0;
@@ -82,6 +90,8 @@ struct svo_context {
     // hipGraph replay of the frame's launch list (one executable graph per results-ring slot: the slot fixes the pointer table,
     // the result record and the copies; re-captured when the stride or the LK grid size changes)
     bool use_graph = false;
+    bool capturing = false;                      // inside hipStreamBeginCapture / EndCapture
+    bool counted = false;                        // this context is in its device's LkGate count
     bool stage_timing = false;                   // record the four stage-boundary events of a frame (svo_set_stage_timing; SVO_STAGE_TIMING=1)
     hipGraphExec_t gexec[SVO_RING] = {};
     int g_stride[SVO_RING] = {}, g_gn[SVO_RING] = {};
@@ -196,6 +206,10 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
         // the default and the graph is the option.
         const char* e = getenv("SVO_GRAPH");
         c->use_graph = e ? atoi(e) != 0 : false;
+        if (device >= 0 && device < SVO_MAX_DEVICES && n_seq > SVO_LONE_MAX_SEQ) {
+            std::lock_guard<std::mutex> lock(g_lk_gate[device].mu);
+            g_lk_gate[device].contexts++; c->counted = true;
+        }
         const char* t = getenv("SVO_STAGE_TIMING");
         c->stage_timing = t ? atoi(t) != 0 : false;
     }
@@ -208,8 +222,18 @@ extern "C" int svo_create(const svo_config* cfg, int device, int n_seq, int widt
     return ctx_create(cfg, device, n_seq, width, height, 0, out);
 }
 
+static bool lk_gated(const svo_context* c) {
+    static const bool off = getenv("SVO_LK_GATE") && atoi(getenv("SVO_LK_GATE")) == 0;
+    return !off && c->counted && g_lk_gate[c->device].contexts > 1;
+}
+
 extern "C" void svo_destroy(svo_context* c) {
     if (!c) return;
+    if (c->counted) {
+        LkGate& g = g_lk_gate[c->device];
+        std::lock_guard<std::mutex> lock(g.mu);
+        if (--g.contexts == 0 && g.ev) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); (void)hipEventDestroy(g.ev); g.ev = nullptr; g.armed = false; }
+    }
     // teardown is best effort: errors here have nowhere to go, the calls are (void)ed on purpose
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -271,9 +295,22 @@ static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_e
     if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
     launch_detect(d, 0, -1, s);
     launch_detect(d, 1, -1, s);
+    const bool gated = !c->capturing && lk_gated(c);
+    if (gated) {
+        LkGate& g = g_lk_gate[c->device];
+        std::lock_guard<std::mutex> lock(g.mu);
+        if (g.armed) HIPCHK(hipStreamWaitEvent(s, g.ev, 0));
+    }
     if (with_events) HIPCHK(hipEventRecord(c->ev_lk0[slot], s));
     launch_lk_chain(d, gn, s);
     if (with_events) HIPCHK(hipEventRecord(c->ev_lk1[slot], s));
+    if (gated) {
+        LkGate& g = g_lk_gate[c->device];
+        std::lock_guard<std::mutex> lock(g.mu);
+        if (!g.ev) HIPCHK(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(g.ev, s));
+        g.armed = true;
+    }
     launch_compact(d, s);
     launch_triangulate(d, s);
     if (with_events) HIPCHK(hipEventRecord(c->ev_tri[slot], s));
@@ -305,7 +342,9 @@ static int enqueue_frame(svo_context* c, const uint8_t* const* left_dev, const u
             hipGraph_t g = nullptr;
             bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
+                c->capturing = true;
                 const int rc = issue_frame(c, slot, stride, gn, false);
+                c->capturing = false;
                 ok = (hipStreamEndCapture(s, &g) == hipSuccess) && rc == SVO_OK && g;
             }
             if (ok) ok = hipGraphInstantiate(&c->gexec[slot], g, nullptr, nullptr, 0) == hipSuccess;

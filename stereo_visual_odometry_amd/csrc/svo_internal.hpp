@@ -95,7 +95,9 @@ __host__ __device__ inline size_t fastimg_index(const DevBuffers& d, int seq, in
 // Hypotheses of the first RANSAC chunk (always solved).  16 when many sequences share the GPU; 32 for a lone stream: the GPU is
 // empty then, a wider chunk costs no time, and the adaptive loop (11-27 iterations with 30 % outliers) rarely needs a second
 // EPnP launch — which would be another 145 us on the critical path.
-__host__ __device__ inline int pnp_first_chunk(const DevBuffers& d) { const int c = d.B <= 8 ? 32 : 16; return d.K < c ? d.K : c; }
+#define SVO_LONE_MAX_SEQ 8      // contexts of up to this many sequences are tuned for latency (wider first RANSAC chunk, 16 lanes per hypothesis ...)
+#define SVO_MAX_DEVICES 64
+__host__ __device__ inline int pnp_first_chunk(const DevBuffers& d) { const int c = d.B <= SVO_LONE_MAX_SEQ ? 32 : 16; return d.K < c ? d.K : c; }
 
 // ---- launchers (each enqueues on `s`; none synchronises) ----
 void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs /* [2][B] device-readable array */, int stride_bytes, hipStream_t s,

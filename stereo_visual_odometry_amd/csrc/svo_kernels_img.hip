@@ -451,15 +451,18 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_bucket_emit(DevBuffers d, int 
             }
         }
     }
-    // ---- the last block of the sequence to get here publishes the result
-    __threadfence();
+    // ---- the last block of the sequence to get here publishes the result.  Every block has read the state it needs by now, so
+    // the ticket needs no fence — except when a second pass follows (every block can tell: it knows the total), where the last
+    // block reads the features the others wrote.  (An agent-scope fence writes back and invalidates the XCD's L2: thousands of
+    // them per frame cost the LK kernel of the other context a third of its speed.)
+    const int total = all < d.CAP ? all : d.CAP;
+    const bool second = pass == 0 && total < d.cfg.pre_matching_feature_threshold;               // vo.cpp:327
+    if (second) __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) sh_last = atomicAdd(&d.emit_ticket[seq], 1) == (int)gridDim.x - 1;
     __syncthreads();
     if (!sh_last) return;
-    __threadfence();
-    const int total = all < d.CAP ? all : d.CAP;
-    const bool second = pass == 0 && total < d.cfg.pre_matching_feature_threshold;               // vo.cpp:327
+    if (second) __threadfence();
     for (int r = threadIdx.x; r < bah; r += EMIT_THREADS) rowcnt[r] = 0;
     if (threadIdx.x == 0) {
         d.emit_ticket[seq] = 0;

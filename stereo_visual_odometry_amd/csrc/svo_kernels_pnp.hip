@@ -104,7 +104,7 @@ static __device__ void svd4_null_vector(const double (&A)[4][4], double (&X)[4])
 static __device__ void pnp_draw_subsets(const DevBuffers& d, SeqState& s, int seq, int upto);
 // `lanes` tracks per wave: 64 when many sequences fill the GPU; 16 when a single stream runs alone — the Jacobi sweeps of a wave
 // last as long as its slowest lane needs, so with the GPU nearly empty fewer tracks per wave shorten the kernel (same results).
-__global__ __launch_bounds__(64) void k_triangulate(DevBuffers d, int lanes) {
+static __device__ __forceinline__ void triangulate_body(const DevBuffers& d, int lanes) {
     const int seq = blockIdx.y;
     SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
@@ -131,9 +131,18 @@ __global__ __launch_bounds__(64) void k_triangulate(DevBuffers d, int lanes) {
     const float scale = Wh != 0.f ? 1.f / Wh : 1.f;                                             // convertPointsFromHomogeneous
     d.world[3 * o] = X * scale; d.world[3 * o + 1] = Y * scale; d.world[3 * o + 2] = Z * scale;
 }
+// Two builds (here and for EPnP and the final refine below).  An LK wave holds 104 registers and four of them share a SIMD: 96
+// registers stay free.  A kernel that needs more cannot start beside the LK grid of another context — it waits until that grid
+// drains (traced: k_pnp_epnp 7.5 ms instead of 0.2, k_pnp_final 8.3 ms instead of 0.1) and everything behind it in the stream
+// with it.  The `_lean` builds are capped at 96 registers (amdgpu_num_vgpr counts VGPR + AGPR pairs on gfx950) and spill to
+// scratch: slower alone, but they run under the other context's LK instead of after it.  Many-sequence contexts use them.
+__global__ __launch_bounds__(64) void k_triangulate(DevBuffers d, int lanes) { triangulate_body(d, lanes); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void k_triangulate_lean(DevBuffers d, int lanes) { triangulate_body(d, lanes); }
 void launch_triangulate(const DevBuffers& d, hipStream_t st) {
-    const int lanes = d.B <= 8 ? 16 : 64;
-    hipLaunchKernelGGL(k_triangulate, dim3((d.CAP + lanes - 1) / lanes + 1, d.B), dim3(64), 0, st, d, lanes);
+    const bool lean = d.B > SVO_LONE_MAX_SEQ;
+    const int lanes = lean ? 64 : 16;
+    if (lean) hipLaunchKernelGGL(k_triangulate_lean, dim3((d.CAP + lanes - 1) / lanes + 1, d.B), dim3(64), 0, st, d, lanes);
+    else hipLaunchKernelGGL(k_triangulate, dim3((d.CAP + lanes - 1) / lanes + 1, d.B), dim3(64), 0, st, d, lanes);
 }
 
 // ------------------------------------------------------------------------------------------------ subsets (cv::RNG, getSubset)
@@ -193,6 +202,7 @@ void launch_pnp_subsets(const DevBuffers& d, hipStream_t st) {
 // bit-identical to the sequential round-robin loop.  The three beta approximations (N = 4, 2, 3 null vectors) are
 // independent after L and rho and run on lanes 0..2.
 #define EP_G 8                                   // lanes per hypothesis, many sequences (k_pnp_epnp_lean); 64 / EP_G hypotheses per block
+#define EP_LEAN_LDS ((64 / EP_G) * EP_STRIDE * sizeof(double))
 #define EP_G_LONE 16                             // lanes per hypothesis when few sequences run (k_pnp_epnp): see rotate_pair12_sides
 #define EP_STRIDE 1032                           // doubles per hypothesis (+8 pad: distinct LDS banks per hypothesis)
 // arena map (doubles)
@@ -456,7 +466,7 @@ static __device__ double epnp_compute_R_and_t(const double* ar, const double* be
 }
 
 // phase 1 (one lane): control points, barycentric coordinates, M, MtM -> arena; W = squared row norms, Vt = I
-static __device__ void epnp_setup(double* ar, double fu, double fv, double uc, double vc) {
+static __device__ __attribute__((always_inline)) void epnp_setup(double* ar, double fu, double fv, double uc, double vc) {
     const int n = 5;
     double* pws = ar + EA_PWS; double* us = ar + EA_US; double* alphas = ar + EA_AL; double* cws = ar + EA_CWS;
     for (int j = 0; j < 3; j++) cws[j] = 0;
@@ -584,7 +594,7 @@ static __device__ void epnp_rho(double* ar) {
 }
 
 // phase 4 (lanes 0..2): beta approximation `branch` (1: N=4 null vectors, 2: N=2, 3: N=3), Gauss-Newton, R, t, error
-static __device__ void epnp_branch(double* ar, int branch, double fu, double fv, double uc, double vc) {
+static __device__ __attribute__((always_inline)) void epnp_branch(double* ar, int branch, double fu, double fv, double uc, double vc) {
     const double* L = ar + EA_L; const double* rho = ar + EA_RHO;
     double* ws = ar + EA_BR + (branch - 1) * EA_BRSZ;
     double* Lx = ws + 70; double* bx = ws + 100; double* be = ws + 106;       // svd workspace occupies ws[0, 60)
@@ -715,9 +725,9 @@ __global__ __launch_bounds__(64) void k_pnp_epnp(DevBuffers d, int h0, int h1) {
     __shared__ double arena[(64 / EP_G_LONE) * EP_STRIDE];
     pnp_epnp_body<EP_G_LONE>(d, h0, h1, arena);
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void k_pnp_epnp_lean(DevBuffers d, int h0, int h1) {
-    __shared__ double arena[(64 / EP_G) * EP_STRIDE];
-    pnp_epnp_body<EP_G>(d, h0, h1, arena);
+extern __shared__ double epnp_arena_dyn[];                         // (64 / EP_G) * EP_STRIDE doubles, given at launch
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void k_pnp_epnp_lean(DevBuffers d, int h0, int h1) {
+    pnp_epnp_body<EP_G>(d, h0, h1, epnp_arena_dyn);
 }
 
 // ------------------------------------------------------------------------------------------------ hypothesis scoring
@@ -833,8 +843,9 @@ __global__ void k_pnp_decide(DevBuffers d, int c0) {
     pnp_draw_subsets(d, s, seq, s.pnp_need);                         // the subsets of the hypotheses the loop can still reach
 }
 
-#define PF_THREADS 512
-#define PF_WAVES (PF_THREADS / 64)
+#define PF_THREADS 512                           // lone stream; the lean build runs PF_THREADS_LEAN
+#define PF_THREADS_LEAN 256
+#define PF_WAVES (PF_THREADS / 64)                // LDS arrays are sized for the larger block
 // the value of lane (dpp-permuted) of a double: DPP works on 32-bit registers, so move the halves separately
 static __device__ __forceinline__ double dpp_f64(double v, const int ctrl_unused);
 template <int CTRL> static __device__ __forceinline__ double dpp_f64_t(double v) {
@@ -936,7 +947,8 @@ static __device__ __forceinline__ void lm_point(double X, double Y, double Z, do
 
 // one evaluation of residuals and Jacobians over the inliers at sh.R / sh.dRdr / sh.param[3..5]; totals land in sh.red[0][*],
 // visible to wave 0 on return (the caller's barrier publishes what thread 0 does with them)
-static __device__ void lm_eval(const DevBuffers& d, const SeqState& s, size_t o, int n, const LmPoints& pts, LmShared& sh) {
+template <int THREADS>
+static __device__ __forceinline__ void lm_eval(const DevBuffers& d, const SeqState& s, size_t o, int n, const LmPoints& pts, LmShared& sh) {
     const double fx = s.K[0], fy = s.K[4], cx = s.K[2], cy = s.K[5];
     double acc[28];
 #pragma unroll
@@ -946,7 +958,7 @@ static __device__ void lm_eval(const DevBuffers& d, const SeqState& s, size_t o,
 #pragma unroll
     for (int k = 0; k < LM_CACHED; k++)
         if (pts.in[k]) lm_point(pts.X[k], pts.Y[k], pts.Z[k], pts.u[k], pts.v[k], R, dRdr, t0, t1, t2, fx, fy, cx, cy, acc);
-    for (int i = threadIdx.x + LM_CACHED * PF_THREADS; i < n; i += PF_THREADS) {        // more tracks than the registers hold
+    for (int i = threadIdx.x + LM_CACHED * THREADS; i < n; i += THREADS) {              // more tracks than the registers hold
         if (!d.inlier[o + i]) continue;
         const float2 c = d.tl1[o + i];
         lm_point(d.world[3 * (o + i)], d.world[3 * (o + i) + 1], d.world[3 * (o + i) + 2], c.x, c.y, R, dRdr, t0, t1, t2, fx, fy, cx, cy, acc);
@@ -959,13 +971,13 @@ static __device__ void lm_eval(const DevBuffers& d, const SeqState& s, size_t o,
     if (threadIdx.x < 28) {                                            // wave 0 alone goes on: its thread 0 runs the state machine
         double t = sh.red[0][threadIdx.x];
 #pragma unroll
-        for (int w = 1; w < PF_WAVES; w++) t += sh.red[w][threadIdx.x];
+        for (int w = 1; w < THREADS / 64; w++) t += sh.red[w][threadIdx.x];
         sh.red[0][threadIdx.x] = t;
     }
     if (wv == 0) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 }
 
-static __device__ void lm_step(LmShared& sh) {
+static __device__ __attribute__((always_inline)) void lm_step(LmShared& sh) {
     const double lambda = sh.lambda_tab[sh.lambdaLg10 + 16];          // exp(lambdaLg10 * log(10)), tabulated by the host
     double A[36], x[6];
     for (int i = 0; i < 36; i++) A[i] = sh.JtJ[i];
@@ -985,7 +997,8 @@ __device__ __forceinline__ void inverse_transform(const double* R, const double*
     T[12] = T[13] = T[14] = 0; T[15] = 1;
 }
 
-__global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
+template <int THREADS>
+static __device__ __forceinline__ void pnp_final_body(const DevBuffers& d) {
     const int seq = blockIdx.x;
     SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
@@ -1020,7 +1033,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
         const double fx = s.K[0], fy = s.K[4], cx = s.K[2], cy = s.K[5];
         const double thr = (double)d.cfg.ransac_reprojection_error;
         const float thr2 = (float)(thr * thr);
-        for (int i = threadIdx.x; i < n; i += PF_THREADS)
+        for (int i = threadIdx.x; i < n; i += THREADS)
             d.inlier[o + i] = direct ? (uint8_t)1 : (uint8_t)point_is_inlier(bestRt, fx, fy, cx, cy, d.world + 3 * (o + i), d.tl1[o + i], thr2);
     }
     __syncthreads();
@@ -1028,7 +1041,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
     LmPoints pts;
 #pragma unroll
     for (int k = 0; k < LM_CACHED; k++) {
-        const int i = threadIdx.x + k * PF_THREADS;
+        const int i = threadIdx.x + k * THREADS;
         pts.in[k] = i < n && d.inlier[o + i];
         const int ii = i < n ? i : 0;
         const float2 c = d.tl1[o + ii];
@@ -1051,7 +1064,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
     for (int guard = 0; guard < 1000; guard++) {
         const int mode = sh.mode;
         if (mode == 2) break;
-        lm_eval(d, s, o, n, pts, sh);
+        lm_eval<THREADS>(d, s, o, n, pts, sh);
         if (threadIdx.x == 0) {
             bool take_J = false;
             if (mode == 1) {                               // CALC_J at the start point
@@ -1086,7 +1099,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
     }
     // ---- count inliers, update the feature set to the inliers at their T1 positions (vo.cpp:115-121)
     const int fb = s.feat_buf;
-    const int chunk = (n + PF_THREADS - 1) / PF_THREADS;
+    const int chunk = (n + THREADS - 1) / THREADS;
     const int i0 = threadIdx.x * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
     int cnt = 0;
     for (int i = i0; i < i1; i++) cnt += d.inlier[o + i];
@@ -1095,7 +1108,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
     for (int k = 1; k < 64; k <<= 1) { int t = __shfl_up(incl, k); if (lane >= k) incl += t; }
     if (lane == 63) sh.wave_tot[wv] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < PF_WAVES; i++) { int t = sh.wave_tot[i]; sh.wave_tot[i] = acc; acc += t; } sh.total = acc; }
+    if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < (THREADS / 64); i++) { int t = sh.wave_tot[i]; sh.wave_tot[i] = acc; acc += t; } sh.total = acc; }
     __syncthreads();
     const int n_inl = sh.total;
     if (threadIdx.x == 0) {
@@ -1106,7 +1119,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
     }
     if (n_inl < d.cfg.features_threshold) {                                                      // vo.cpp:106-113
         // the reference builds its is_ok vector only past this gate (vo.cpp:115): on this path no inlier flags exist
-        for (int i = threadIdx.x; i < n; i += PF_THREADS) d.inlier[o + i] = 0;
+        for (int i = threadIdx.x; i < n; i += THREADS) d.inlier[o + i] = 0;
         if (threadIdx.x == 0) s.fail_reason = 3;
         return;
     }
@@ -1133,6 +1146,8 @@ __global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) {
         s.ok = 1;
     }
 }
+__global__ __launch_bounds__(PF_THREADS) void k_pnp_final(DevBuffers d) { pnp_final_body<PF_THREADS>(d); }
+__global__ __launch_bounds__(PF_THREADS_LEAN) __attribute__((amdgpu_num_vgpr(48))) void k_pnp_final_lean(DevBuffers d) { pnp_final_body<PF_THREADS_LEAN>(d); }
 
 // ------------------------------------------------------------------------------------------------ four points: P3P
 // cv::solvePnPRansac with exactly four points solves ONE P3P (Gao, Hou, Tang, Chang, PAMI 2003, as OpenCV's p3p.cpp does it:
@@ -1374,16 +1389,21 @@ void launch_inverse_transform(const double* R, const double* t, double* T, hipSt
 void launch_pnp(const DevBuffers& d, hipStream_t st) {
     // the subsets were drawn by the last block of k_triangulate (stage entry points go through launch_triangulate too)
     const int c0 = pnp_first_chunk(d);
-    const bool lean = d.B > 8;                                       // see k_pnp_epnp_lean
+    const bool lean = d.B > SVO_LONE_MAX_SEQ;                                       // see k_pnp_epnp_lean
+    if (lean) {                                                      // more than the 64 KB a kernel gets without asking
+        static const hipError_t once = hipFuncSetAttribute((const void*)k_pnp_epnp_lean, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EP_LEAN_LDS);
+        (void)once;
+    }
     const int hpb = 64 / (lean ? EP_G : EP_G_LONE);
-    if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((c0 + hpb - 1) / hpb, d.B), dim3(64), 0, st, d, 0, c0);
+    if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((c0 + hpb - 1) / hpb, d.B), dim3(64), EP_LEAN_LDS, st, d, 0, c0);
     else hipLaunchKernelGGL(k_pnp_epnp, dim3((c0 + hpb - 1) / hpb, d.B), dim3(64), 0, st, d, 0, c0);
     hipLaunchKernelGGL(k_pnp_score, dim3(c0, d.B), dim3(256), 0, st, d, 0, c0);
     if (d.K > c0) {
         hipLaunchKernelGGL(k_pnp_decide, dim3((d.B + 63) / 64), dim3(64), 0, st, d, c0);
-        if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((d.K - c0 + hpb - 1) / hpb, d.B), dim3(64), 0, st, d, c0, d.K);
+        if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((d.K - c0 + hpb - 1) / hpb, d.B), dim3(64), EP_LEAN_LDS, st, d, c0, d.K);
         else hipLaunchKernelGGL(k_pnp_epnp, dim3((d.K - c0 + hpb - 1) / hpb, d.B), dim3(64), 0, st, d, c0, d.K);
         hipLaunchKernelGGL(k_pnp_score, dim3(d.K - c0, d.B), dim3(256), 0, st, d, c0, d.K);
     }
-    hipLaunchKernelGGL(k_pnp_final, dim3(d.B), dim3(PF_THREADS), 0, st, d);
+    if (lean) hipLaunchKernelGGL(k_pnp_final_lean, dim3(d.B), dim3(PF_THREADS_LEAN), 0, st, d);
+    else hipLaunchKernelGGL(k_pnp_final, dim3(d.B), dim3(PF_THREADS), 0, st, d);
 }
