@@ -246,7 +246,7 @@ def main():
         traffic = None; traffic_src = None
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_lk_chain_pmc.json")))
-        profiled = args.workload == "cfg2" and win == 21          # the committed counter passes are of this workload's kernel
+        profiled = args.workload == "cfg2" and win == 21 and abs(args.movers - 0.3) < 1e-9   # the committed counter passes are of this workload's kernel on this scene
         if pmcs and profiled:
             try:
                 j = json.load(open(pmcs[-1]))

@@ -289,6 +289,7 @@ static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_e
     DevBuffers& d = c->d;
     const int B = d.B;
     hipStream_t s = c->stream;
+    d.co_resident = lk_gated(c) ? 1 : 0;                              // picks the 96-register builds of the f64 kernels (svo_kernels_pnp.hip)
     const uint8_t** dp = d.img_ptrs + (size_t)slot * 2 * B;         // the slot's pointer table: pinned host memory the kernel reads in place
     launch_ingest(d, dp, stride, s, true);                            // + the per-frame reset
     launch_pyramid(d, s);

@@ -60,6 +60,7 @@ struct DevBuffers {
     unsigned long long* bucket_keys;           // [B][NB]
     int* bucket_rowcnt;                        // [B][buckets_along_height] occupied buckets per grid row (counted at first fill)
     int* emit_ticket;                          // [B] blocks of k_bucket_emit that have finished; keys, row counts and tickets are all zero between passes
+    int co_resident;                           // several many-sequence contexts share this device: launch the 96-register builds
     // features_per_bucket > 1 only (the general Bucket::add_feature walk; the default capacity 1 is an argmax and needs none of it):
     int KPCAP;                                 // candidate capacity per sequence = CAP (existing tracks) + keypoints one FAST pass can return
     uint8_t* score;                            // [B][W*H] NMS-surviving FAST scores of the pass

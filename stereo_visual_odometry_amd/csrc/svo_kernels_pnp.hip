@@ -135,12 +135,13 @@ static __device__ __forceinline__ void triangulate_body(const DevBuffers& d, int
 // registers stay free.  A kernel that needs more cannot start beside the LK grid of another context — it waits until that grid
 // drains (traced: k_pnp_epnp 7.5 ms instead of 0.2, k_pnp_final 8.3 ms instead of 0.1) and everything behind it in the stream
 // with it.  The `_lean` builds are capped at 96 registers (amdgpu_num_vgpr counts VGPR + AGPR pairs on gfx950) and spill to
-// scratch: slower alone, but they run under the other context's LK instead of after it.  Many-sequence contexts use them.
+// scratch: slower alone (32 sequences, one context: EPnP 202 -> 286 us, final 90 -> 362 us), but they run under the other
+// context's LK instead of after it.  Used when several many-sequence contexts share the device (DevBuffers::co_resident).
 __global__ __launch_bounds__(64) void k_triangulate(DevBuffers d, int lanes) { triangulate_body(d, lanes); }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void k_triangulate_lean(DevBuffers d, int lanes) { triangulate_body(d, lanes); }
 void launch_triangulate(const DevBuffers& d, hipStream_t st) {
-    const bool lean = d.B > SVO_LONE_MAX_SEQ;
-    const int lanes = lean ? 64 : 16;
+    const bool lean = d.co_resident;
+    const int lanes = d.B > SVO_LONE_MAX_SEQ ? 64 : 16;
     if (lean) hipLaunchKernelGGL(k_triangulate_lean, dim3((d.CAP + lanes - 1) / lanes + 1, d.B), dim3(64), 0, st, d, lanes);
     else hipLaunchKernelGGL(k_triangulate, dim3((d.CAP + lanes - 1) / lanes + 1, d.B), dim3(64), 0, st, d, lanes);
 }
@@ -717,10 +718,9 @@ static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0
     }
 }
 
-// Two builds of the same body.  The register-resident linear algebra makes the kernel want ~316 VGPRs: that is the fastest
-// form when a single stream runs alone (latency), but with many sequences its waves sit beside the other context's LK waves,
-// and every 104 registers they hold is one LK wave less per SIMD.  The lean build is limited to the architected 128 VGPRs
-// (+ AGPR spill space, 257 in all): measured +2.4 % whole-job rate at 256 sequences, same results.
+// Two builds (see k_triangulate_lean): the register-resident linear algebra wants ~316 registers, 16 lanes per hypothesis; the
+// lean build (96 registers, 8 lanes per hypothesis, arena in dynamic LDS — with a static 66 KB arena the compiler ties the
+// register budget to the occupancy the LDS allows and ignores the cap) is for contexts that share the GPU with another's LK.
 __global__ __launch_bounds__(64) void k_pnp_epnp(DevBuffers d, int h0, int h1) {
     __shared__ double arena[(64 / EP_G_LONE) * EP_STRIDE];
     pnp_epnp_body<EP_G_LONE>(d, h0, h1, arena);
@@ -1389,7 +1389,7 @@ void launch_inverse_transform(const double* R, const double* t, double* T, hipSt
 void launch_pnp(const DevBuffers& d, hipStream_t st) {
     // the subsets were drawn by the last block of k_triangulate (stage entry points go through launch_triangulate too)
     const int c0 = pnp_first_chunk(d);
-    const bool lean = d.B > SVO_LONE_MAX_SEQ;                                       // see k_pnp_epnp_lean
+    const bool lean = d.co_resident;                                 // see k_triangulate_lean
     if (lean) {                                                      // more than the 64 KB a kernel gets without asking
         static const hipError_t once = hipFuncSetAttribute((const void*)k_pnp_epnp_lean, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EP_LEAN_LDS);
         (void)once;
