@@ -1390,9 +1390,13 @@ void launch_pnp(const DevBuffers& d, hipStream_t st) {
     // the subsets were drawn by the last block of k_triangulate (stage entry points go through launch_triangulate too)
     const int c0 = pnp_first_chunk(d);
     const bool lean = d.co_resident;                                 // see k_triangulate_lean
-    if (lean) {                                                      // more than the 64 KB a kernel gets without asking
-        static const hipError_t once = hipFuncSetAttribute((const void*)k_pnp_epnp_lean, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EP_LEAN_LDS);
-        (void)once;
+    if (lean) {                                                      // more than the 64 KB a kernel gets without asking; per device
+        static bool asked[SVO_MAX_DEVICES];
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < SVO_MAX_DEVICES && !asked[dev]) {
+            (void)hipFuncSetAttribute((const void*)k_pnp_epnp_lean, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EP_LEAN_LDS);
+            asked[dev] = true;
+        }
     }
     const int hpb = 64 / (lean ? EP_G : EP_G_LONE);
     if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((c0 + hpb - 1) / hpb, d.B), dim3(64), EP_LEAN_LDS, st, d, 0, c0);
