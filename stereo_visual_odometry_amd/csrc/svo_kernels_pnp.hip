@@ -204,7 +204,7 @@ void launch_pnp_subsets(const DevBuffers& d, hipStream_t st) {
 // independent after L and rho and run on lanes 0..2.
 #define EP_G 8                                   // lanes per hypothesis, many sequences (k_pnp_epnp_lean); 64 / EP_G hypotheses per block
 #define EP_LEAN_LDS ((64 / EP_G) * EP_STRIDE * sizeof(double))
-#define EP_G_LONE 16                             // lanes per hypothesis when few sequences run (k_pnp_epnp): see rotate_pair12_sides
+#define EP_G_LONE 32                             // lanes per hypothesis when few sequences run (k_pnp_epnp): see rotate_pair12_quads
 #define EP_STRIDE 1032                           // doubles per hypothesis (+8 pad: distinct LDS banks per hypothesis)
 // arena map (doubles)
 #define EA_AT 0                                  // 144  MtM, then the rotating rows
@@ -253,53 +253,73 @@ static __device__ bool rotate_pair12(double* At, double* Wv, double* Vt, int i, 
     return true;
 }
 
-// The same rotation with the work of one pair on TWO lanes: both compute p, c and s from the rows of At (identical bits), then one
-// rotates the rows of At and sums the new squared norms, the other rotates the rows of Vt — one instruction stream, half the
-// rotation work on the critical path of a lone stream.  The lanes of a pair sit in one wave: every read of At for p precedes, in
-// program order, the first write of the rotated rows.
-static __device__ bool rotate_pair12_sides(double* At, double* Wv, double* Vt, int i, int j, bool vside) {
-    // A lone wave per SIMD hides no latency: every dependent f64 instruction waits for its operand (~8 cycles against 4 to issue).
-    // The compiler orders for register pressure, not for this, so the order is pinned with sched_barrier: independent products
-    // first, and the rotation software-pipelined (products of element k, sums of k-1, squares of k-2, norms of k-3 per step).
+// the value a DPP control brings from another lane, for a double (DPP moves 32-bit registers: the halves go separately)
+template <int CTRL> static __device__ __forceinline__ double dpp_move_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// The rotation of one pair on FOUR lanes (32 lanes per hypothesis), for a lone stream.  Two SIDES: both compute p, c and s from
+// the rows of At (identical bits), then one side rotates the rows of At and sums the new squared norms, the other rotates the rows
+// of Vt — one instruction stream; every read of At for p precedes, in program order, the first write of the rotated rows (the
+// lanes of a pair sit in one wave).  Two HALVES per side: each side's twelve elements are split over neighbouring lanes.
+// A lone wave per SIMD hides no latency and the compiler orders for register pressure, so the order is pinned with
+// sched_barrier: loads, the row-norm square root under them, independent products, then the rotation software-pipelined
+// (products of element k, sums of k-1, squares of k-2, norms of k-3 per step).  Every sum keeps its element order 0..11: the lower half sums its six terms from zero, hands
+// the partial to its neighbour (DPP row_shr:1), which continues with elements 6..11 — bit for bit the sequential sum — and, for
+// p, hands the total back (row_shl:1).  Per lane 6 instead of 12 elements to load, multiply, rotate, square and store; the two
+// hand-overs cost 12 instructions.
+static __device__ bool rotate_pair12_quads(double* At, double* Wv, double* Vt, int i, int j, bool vside, int half) {
     const double eps = SVO_DBL_EPS * 10;
-    const int oi = __mul24(i, 12), oj = __mul24(j, 12);               // (a full 32-bit multiply is a quarter-rate instruction)
+    const int oi = __mul24(i, 12) + half * 6, oj = __mul24(j, 12) + half * 6;
     const double* Ai = At + oi; const double* Aj = At + oj;
-    double a = Wv[i], p = 0, b = Wv[j], c, s;
-    double ai[12], aj[12], pr[12];
+    double a = Wv[i], b = Wv[j], c, s;
+    double ai[6], aj[6], pr[6];
 #pragma unroll
-    for (int k = 0; k < 12; k++) { ai[k] = Ai[k]; aj[k] = Aj[k]; }
+    for (int k = 0; k < 6; k++) { ai[k] = Ai[k]; aj[k] = Aj[k]; }
     __builtin_amdgcn_sched_barrier(0);
     const double lim = eps * sqrt(a * b);                             // while the rows arrive from LDS
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 12; k++) pr[k] = ai[k] * aj[k];
+    for (int k = 0; k < 6; k++) pr[k] = ai[k] * aj[k];
     __builtin_amdgcn_sched_barrier(0);
+    double plo = 0;
 #pragma unroll
-    for (int k = 0; k < 12; k++) p += pr[k];
+    for (int k = 0; k < 6; k++) plo += pr[k];                         // lower half: elements 0..5 from zero
+    double pup = dpp_move_f64<0x111>(plo);                            // row_shr:1 -> the upper half continues its neighbour's partial
+#pragma unroll
+    for (int k = 0; k < 6; k++) pup += pr[k];
+    const double pdn = dpp_move_f64<0x101>(pup);                      // row_shl:1 -> and hands the total back
+    double p = half ? pup : pdn;
     if (fabs(p) <= lim) return false;
     p *= 2;
     double beta = a - b, gamma = sqrt(p * p + beta * beta);
     jacobi_cs(p, beta, gamma, c, s);
     double* X = (vside ? Vt : At) + oi; double* Y = (vside ? Vt : At) + oj;
-    double x[12], y[12];
+    double x[6], y[6];
 #pragma unroll
-    for (int k = 0; k < 12; k++) { x[k] = X[k]; y[k] = Y[k]; }
-    double ma[12], mb[12], mc[12], md[12], t0[12], t1[12], q0[12], q1[12];
-    a = b = 0;
+    for (int k = 0; k < 6; k++) { x[k] = X[k]; y[k] = Y[k]; }
+    double ma[6], mb[6], mc[6], md[6], t0[6], t1[6], q0[6], q1[6];
+    double alo = 0, blo = 0;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int st = 0; st < 15; st++) {
-        if (st < 12) { ma[st] = c * x[st]; mb[st] = s * y[st]; mc[st] = -s * x[st]; md[st] = c * y[st]; }
-        if (st >= 1 && st < 13) { t0[st - 1] = ma[st - 1] + mb[st - 1]; t1[st - 1] = mc[st - 1] + md[st - 1]; }
-        if (st >= 2 && st < 14) { q0[st - 2] = t0[st - 2] * t0[st - 2]; q1[st - 2] = t1[st - 2] * t1[st - 2]; }
-        if (st >= 3) { a += q0[st - 3]; b += q1[st - 3]; }
-        if (st >= 2 && st < 14 && ((st - 2) & 1)) {
+    for (int st = 0; st < 9; st++) {
+        if (st < 6) { ma[st] = c * x[st]; mb[st] = s * y[st]; mc[st] = -s * x[st]; md[st] = c * y[st]; }
+        if (st >= 1 && st < 7) { t0[st - 1] = ma[st - 1] + mb[st - 1]; t1[st - 1] = mc[st - 1] + md[st - 1]; }
+        if (st >= 2 && st < 8) { q0[st - 2] = t0[st - 2] * t0[st - 2]; q1[st - 2] = t1[st - 2] * t1[st - 2]; }
+        if (st >= 3) { alo += q0[st - 3]; blo += q1[st - 3]; }
+        if (st >= 2 && st < 8 && ((st - 2) & 1)) {
             X[st - 3] = t0[st - 3]; X[st - 2] = t0[st - 2]; Y[st - 3] = t1[st - 3]; Y[st - 2] = t1[st - 2];
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    double* Wo = vside ? At + EA_M : Wv;                              // Vt's lanes compute the sums as well (one stream) and drop them in dead space
-    Wo[i] = a; Wo[j] = b;
+    double aup = dpp_move_f64<0x111>(alo), bup = dpp_move_f64<0x111>(blo);
+#pragma unroll
+    for (int k = 0; k < 6; k++) { aup += q0[k]; bup += q1[k]; }
+    double* Wo = (vside || !half) ? At + EA_M : Wv;                   // the upper At lane holds the norms; the others drop theirs in dead space
+    Wo[i] = aup; Wo[j] = bup;
     return true;
 }
 
@@ -663,7 +683,7 @@ static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0
     __syncthreads();
     // ---- 12 x 12 one-sided Jacobi, round-robin ordering: lane q < 6 owns pair q of every round
     bool done = !valid;
-    const int qp = G == 16 ? (q & 7) : q;                               // the pair of the round this lane works on
+    const int qp = G == 32 ? ((q & 15) >> 1) : q;                       // the pair of the round this lane works on
     // round r pairs row pa = 1 + (qp - 1 + r) % 11 (row 0 for pair 0) with row pb = 1 + (10 - qp + r) % 11: both walk the
     // cycle 1..11 one step per round and are back where they started after the 11 rounds of a sweep
     int pa = qp, pb = 11 - qp;
@@ -674,7 +694,7 @@ static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0
             pa = qp == 0 ? 0 : pa == 11 ? 1 : pa + 1;
             pb = pb == 11 ? 1 : pb + 1;
             if (!done && qp < 6) {
-                if (G == 16) changed |= rotate_pair12_sides(ar + EA_AT, ar + EA_W, ar + EA_VT, i, j, q >= 8);
+                if (G == 32) changed |= rotate_pair12_quads(ar + EA_AT, ar + EA_W, ar + EA_VT, i, j, q >= 16, q & 1);
                 else changed |= rotate_pair12(ar + EA_AT, ar + EA_W, ar + EA_VT, i, j);
             }
             __syncthreads();
@@ -718,7 +738,7 @@ static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0
     }
 }
 
-// Two builds (see k_triangulate_lean): the register-resident linear algebra wants ~316 registers, 16 lanes per hypothesis; the
+// Two builds (see k_triangulate_lean): the register-resident linear algebra wants ~300 registers, 32 lanes per hypothesis; the
 // lean build (96 registers, 8 lanes per hypothesis, arena in dynamic LDS — with a static 66 KB arena the compiler ties the
 // register budget to the occupancy the LDS allows and ignores the cap) is for contexts that share the GPU with another's LK.
 __global__ __launch_bounds__(64) void k_pnp_epnp(DevBuffers d, int h0, int h1) {
