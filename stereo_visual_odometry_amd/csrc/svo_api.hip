@@ -291,8 +291,7 @@ static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_e
     hipStream_t s = c->stream;
     d.co_resident = lk_gated(c) ? 1 : 0;                              // picks the 96-register builds of the f64 kernels (svo_kernels_pnp.hip)
     const uint8_t** dp = d.img_ptrs + (size_t)slot * 2 * B;         // the slot's pointer table: pinned host memory the kernel reads in place
-    launch_ingest(d, dp, stride, s, true);                            // + the per-frame reset
-    launch_pyramid(d, s);
+    launch_ingest_pyramid(d, dp, stride, s, true);                    // + the per-frame reset
     if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
     launch_detect(d, 0, -1, s);
     launch_detect(d, 1, -1, s);
@@ -486,8 +485,7 @@ extern "C" int svo_circular_matching(svo_context* c, const uint8_t* left_t1, con
     const uint8_t* l[1] = {left_t1}; const uint8_t* r[1] = {right_t1};
     if ((rc = stage_host_images(c, l, r, stride, lp, rp)) != SVO_OK) return rc;
     const uint8_t** hp = c->h_ptrs; hp[0] = lp[0]; hp[1] = rp[0];
-    launch_ingest(c->d, c->d.img_ptrs, c->d.geom.W * c->d.CN, c->stream, false);
-    launch_pyramid(c->d, c->stream);                                              // vo.cpp:200-201
+    launch_ingest_pyramid(c->d, c->d.img_ptrs, c->d.geom.W * c->d.CN, c->stream, false);          // vo.cpp:200-201
     launch_lk_chain(c->d, n, c->stream);                                          // vo.cpp:203-230
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(pl1, c->d.pl1, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));

@@ -104,6 +104,7 @@ __host__ __device__ inline int pnp_first_chunk(const DevBuffers& d) { const int 
 void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs /* [2][B] device-readable array */, int stride_bytes, hipStream_t s,
                    bool begin_frame /* also run the per-frame reset of stereo_callback */);
 void launch_pyramid(const DevBuffers& d, hipStream_t s);
+void launch_ingest_pyramid(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride_bytes, hipStream_t s, bool begin_frame);   // both, fewer launches
 void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s);   // pass 0: FAST_THRESHOLD, pass 1: /4 if needed; th_override >= 0 replaces it
 void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t s);      // grid_n = max features that can enter LK
 void launch_compact(const DevBuffers& d, hipStream_t s);

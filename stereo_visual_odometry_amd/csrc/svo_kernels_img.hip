@@ -165,11 +165,158 @@ __global__ __launch_bounds__(256) void k_pyrdown(DevBuffers d, int level) {
     }
 }
 
-void launch_pyramid(const DevBuffers& d, hipStream_t st) {
-    for (int l = 1; l < d.geom.nlevels; l++) {
-        dim3 g((d.geom.lv[l].w + PD_TW - 1) / PD_TW, (d.geom.lv[l].h + PD_TH - 1) / PD_TH, d.B * 2 * d.CN);
-        hipLaunchKernelGGL(k_pyrdown, g, dim3(256), 0, st, d, l);
+// ---- fewer launches for the front of a frame (a lone stream is launch-bound there: a 5 us kernel every 4.5 us of host time) ----
+// k_ingest_pyr1: ingest and the first pyrDown in one launch (single-channel contexts).  A block stages the 67 x 19 source tile of
+// its 32 x 8 level-1 outputs straight from the caller's image, writes the 64 x 16 level-0 pixels it owns and the level-1 tile.
+__global__ __launch_bounds__(256) void k_ingest_pyr1(DevBuffers d, const uint8_t* const* srcs, int stride, int begin_frame) {
+    const int seq = blockIdx.z >> 1, cam = blockIdx.z & 1;
+    const LevelInfo ls = d.geom.lv[0], ld = d.geom.lv[1];
+    const uint8_t* src = srcs[cam * d.B + seq];
+    const int slot = begin_frame ? free_slot(d.st[seq]) : d.st[seq].slot_t1;
+    if (begin_frame && blockIdx.x == 0 && blockIdx.y == 0 && cam == 0 && threadIdx.x == 0) frame_begin(d.st[seq]);
+    uint8_t* base = d.pyr + pyr_index(d, seq, slot, cam);
+    uint8_t* l0 = base + ls.off; uint8_t* dst = base + ld.off;
+    constexpr int SW = 2 * PD_TW + 3, SH = 2 * PD_TH + 3;        // 67 x 19 source tile
+    __shared__ __attribute__((aligned(4))) uint8_t tile[SH][SW + 1];
+    __shared__ unsigned short hrow[SH][PD_TW];
+    const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
+    const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
+    struct __attribute__((packed, aligned(1))) UD { unsigned v; };
+    if (sx0 >= 0 && sy0 >= 0 && sx0 + SW + 1 <= ls.w && sy0 + SH <= ls.h) {
+        constexpr int DPR = (SW + 1) / 4;
+        for (int i = threadIdx.x; i < DPR * SH; i += 256) {
+            int ty = i / DPR, c = i - ty * DPR;
+            const unsigned v = reinterpret_cast<const UD*>(src + (size_t)(sy0 + ty) * stride + sx0 + 4 * c)->v;
+            *reinterpret_cast<unsigned*>(&tile[ty][4 * c]) = v;
+        }
+        __syncthreads();
+        {   // the block's own 64 x 16 level-0 pixels: one dword per thread
+            const int ty = threadIdx.x >> 4, c = threadIdx.x & 15;
+            UD u; u.v = (unsigned)tile[ty + 2][4 * c + 2] | ((unsigned)tile[ty + 2][4 * c + 3] << 8) | ((unsigned)tile[ty + 2][4 * c + 4] << 16) | ((unsigned)tile[ty + 2][4 * c + 5] << 24);
+            *reinterpret_cast<UD*>(l0 + (size_t)(2 * oy + ty) * ls.w + 2 * ox + 4 * c) = u;
+        }
+    } else {
+        for (int i = threadIdx.x; i < SW * SH; i += 256) {
+            int ty = i / SW, tx = i - ty * SW;
+            tile[ty][tx] = src[(size_t)reflect101(sy0 + ty, ls.h) * stride + reflect101(sx0 + tx, ls.w)];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * PD_TW * 2 * PD_TH; i += 256) {
+            const int ty = i / (2 * PD_TW), tx = i - ty * (2 * PD_TW);
+            const int gx = 2 * ox + tx, gy = 2 * oy + ty;
+            if (gx < ls.w && gy < ls.h) l0[(size_t)gy * ls.w + gx] = tile[ty + 2][tx + 2];   // in range: the tile holds the pixel itself
+        }
     }
+    for (int i = threadIdx.x; i < SH * PD_TW; i += 256) {
+        int ty = i / PD_TW, x = i - ty * PD_TW;
+        const uint8_t* r = &tile[ty][2 * x];
+        hrow[ty][x] = (unsigned short)(r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4]);
+    }
+    __syncthreads();
+    {
+        int y = threadIdx.x / PD_TW, x = threadIdx.x - y * PD_TW;
+        int gx = ox + x, gy = oy + y;
+        if (gx < ld.w && gy < ld.h) {
+            int v = hrow[2 * y + 2][x] * 6 + (hrow[2 * y + 1][x] + hrow[2 * y + 3][x]) * 4 + hrow[2 * y][x] + hrow[2 * y + 4][x];
+            dst[(size_t)gy * ld.w + gx] = (uint8_t)((v + 128) >> 8);
+        }
+    }
+}
+
+// k_pyrdown2: levels l+1 AND l+2 from level l in one launch.  A block owns a 16 x 8 tile of level l+2, i.e. 32 x 16 of level l+1;
+// it computes the 35 x 19 level-(l+1) pixels its own tile needs (the 3-pixel rim is recomputed by the neighbours: +30 % work on
+// levels that are 1/16 and 1/64 of the image) from a 73 x 41 source tile.  Rim positions outside level l+1 are never read:
+// REFLECT_101 folds them onto positions inside the tile.
+#define P2_TW 16
+#define P2_TH 8
+__global__ __launch_bounds__(256) void k_pyrdown2(DevBuffers d, int level) {
+    const int plane = blockIdx.z % d.CN, sc = blockIdx.z / d.CN;
+    const int seq = sc / 2, cam = sc & 1;
+    const LevelInfo ls = d.geom.lv[level], lm = d.geom.lv[level + 1], ld = d.geom.lv[level + 2];
+    uint8_t* base = d.pyr + pyr_index(d, seq, d.st[seq].slot_t1, cam) + (size_t)plane * d.geom.pyr_bytes;
+    const uint8_t* src = base + ls.off;
+    uint8_t* mid = base + lm.off; uint8_t* dst = base + ld.off;
+    constexpr int MW = 2 * P2_TW + 3, MH = 2 * P2_TH + 3;        // 35 x 19 of the middle level
+    constexpr int SW = 2 * MW + 3, SH = 2 * MH + 3;              // 73 x 41 of the source level
+    __shared__ uint8_t tile[SH][SW + 3];
+    __shared__ unsigned short hrow[SH][MW + 1];
+    __shared__ uint8_t mtile[MH][MW + 1];
+    __shared__ unsigned short hrow2[MH][P2_TW];
+    const int ox = blockIdx.x * P2_TW, oy = blockIdx.y * P2_TH;  // level l+2
+    const int mx0 = 2 * ox - 2, my0 = 2 * oy - 2;                // level l+1
+    const int sx0 = 2 * mx0 - 2, sy0 = 2 * my0 - 2;              // level l
+    for (int i = threadIdx.x; i < SW * SH; i += 256) {
+        int ty = i / SW, tx = i - ty * SW;
+        tile[ty][tx] = src[(size_t)reflect101(sy0 + ty, ls.h) * ls.w + reflect101(sx0 + tx, ls.w)];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SH * MW; i += 256) {
+        int ty = i / MW, x = i - ty * MW;
+        const uint8_t* r = &tile[ty][2 * x];
+        hrow[ty][x] = (unsigned short)(r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MH * MW; i += 256) {
+        int y = i / MW, x = i - y * MW;
+        int v = hrow[2 * y + 2][x] * 6 + (hrow[2 * y + 1][x] + hrow[2 * y + 3][x]) * 4 + hrow[2 * y][x] + hrow[2 * y + 4][x];
+        const uint8_t m = (uint8_t)((v + 128) >> 8);
+        mtile[y][x] = m;
+        const int gx = mx0 + x, gy = my0 + y;
+        if (x >= 2 && x < 2 + 2 * P2_TW && y >= 2 && y < 2 + 2 * P2_TH && gx < lm.w && gy < lm.h) mid[(size_t)gy * lm.w + gx] = m;   // the owned 32 x 16
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MH * P2_TW; i += 256) {
+        int ty = i / P2_TW, x = i - ty * P2_TW;
+        // row / column of the middle tile that holds this (possibly folded) position; outputs beyond the level's edge (never
+        // stored) may fold outside the tile: clamped, so that no index leaves the array
+        int gy = reflect101(my0 + ty, lm.h) - my0;
+        gy = gy < 0 ? 0 : gy > MH - 1 ? MH - 1 : gy;
+        int t[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int gx = reflect101(mx0 + 2 * x + k, lm.w) - mx0;
+            gx = gx < 0 ? 0 : gx > MW - 1 ? MW - 1 : gx;
+            t[k] = mtile[gy][gx];
+        }
+        hrow2[ty][x] = (unsigned short)(t[2] * 6 + (t[1] + t[3]) * 4 + t[0] + t[4]);
+    }
+    __syncthreads();
+    if (threadIdx.x < P2_TW * P2_TH) {
+        int y = threadIdx.x / P2_TW, x = threadIdx.x - y * P2_TW;
+        int gx = ox + x, gy = oy + y;
+        if (gx < ld.w && gy < ld.h) {
+            int v = hrow2[2 * y + 2][x] * 6 + (hrow2[2 * y + 1][x] + hrow2[2 * y + 3][x]) * 4 + hrow2[2 * y][x] + hrow2[2 * y + 4][x];
+            dst[(size_t)gy * ld.w + gx] = (uint8_t)((v + 128) >> 8);
+        }
+    }
+}
+
+// levels first .. nlevels-1 from level first-1: pairs of levels per launch where two remain
+static void launch_pyramid_from(const DevBuffers& d, int first, hipStream_t st) {
+    int l = first;
+    while (l < d.geom.nlevels) {
+        if (l + 1 < d.geom.nlevels) {
+            dim3 g((d.geom.lv[l + 1].w + P2_TW - 1) / P2_TW, (d.geom.lv[l + 1].h + P2_TH - 1) / P2_TH, d.B * 2 * d.CN);
+            hipLaunchKernelGGL(k_pyrdown2, g, dim3(256), 0, st, d, l - 1);
+            l += 2;
+        } else {
+            dim3 g((d.geom.lv[l].w + PD_TW - 1) / PD_TW, (d.geom.lv[l].h + PD_TH - 1) / PD_TH, d.B * 2 * d.CN);
+            hipLaunchKernelGGL(k_pyrdown, g, dim3(256), 0, st, d, l);
+            l += 1;
+        }
+    }
+}
+void launch_pyramid(const DevBuffers& d, hipStream_t st) { launch_pyramid_from(d, 1, st); }
+// ingest + all pyramid levels of the T1 slot (vo.cpp:74-75, 200-201): single-channel contexts fuse the ingest with the first level
+void launch_ingest_pyramid(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride, hipStream_t st, bool begin_frame) {
+    if (d.CN == 1 && d.geom.nlevels >= 2) {
+        dim3 g((d.geom.lv[1].w + PD_TW - 1) / PD_TW, (d.geom.lv[1].h + PD_TH - 1) / PD_TH, d.B * 2);
+        hipLaunchKernelGGL(k_ingest_pyr1, g, dim3(256), 0, st, d, left_right_dev_ptrs, stride, (int)begin_frame);
+        launch_pyramid_from(d, 2, st);
+        return;
+    }
+    launch_ingest(d, left_right_dev_ptrs, stride, st, begin_frame);
+    launch_pyramid(d, st);
 }
 
 // ------------------------------------------------------------------------------------------------
