@@ -641,7 +641,9 @@ __device__ __forceinline__ LkCrit make_crit(const svo_config& c, float mineig_cu
 // Measured on MI355X, 32 sequences per launch (rocprofv3 FETCH_SIZE per launch / HIP-event time):
 //   chunk 1: 340 MB / 1.90 ms    4: 214 / 1.91    16: 174 / 1.94    64: 118 / 2.18    whole eighths: 61 / 2.79
 //   affine: 39 MB / 2.02 ms.  The kernel is VALU-bound and the fetches are served by the Infinity Cache, so the default
-//   (SVO_LK_CHUNK=8) takes the traffic reduction that is free; the others stay selectable.
+//   takes a traffic reduction that is free; the others stay selectable.  Round 1 chose 8; re-measured at the end of round 2 at
+//   the default bench configuration (two contexts of 128 sequences, A/B in one call): 4 is 0.5-0.7 % faster than 8 on both the
+//   mover and the static scene (1, 2 and 4 tie), 16 is 1.8 % slower: default 4.
 #define LK_MAP_STRIPE 0
 #define LK_MAP_AFFINE 1
 #define LK_MAP_INTERLEAVED 2
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(64) void k_lk_single(DevBuffers d, int slotA, int c
 }
 
 #define LK_MAX_GRID 16384
-static int lk_chunk() { static int v = -1; if (v < 0) { const char* e = getenv("SVO_LK_CHUNK"); v = e ? atoi(e) : 8; if (v < 1) v = 1; if (v > 2048) v = 2048; } return v; }
+static int lk_chunk() { static int v = -1; if (v < 0) { const char* e = getenv("SVO_LK_CHUNK"); v = e ? atoi(e) : 4; if (v < 1) v = 1; if (v > 2048) v = 2048; } return v; }
 static int lk_xcd_mapping() { static int v = -1; if (v < 0) { const char* e = getenv("SVO_LK_XCD"); v = e ? atoi(e) : 0; } return v; }
 // (window, lanes per feature) instantiations; the FIRST entry of a window is its default, the others are selectable with
 // SVO_LK_G=<lanes> for measurement.
