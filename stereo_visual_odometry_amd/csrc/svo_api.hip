@@ -289,7 +289,8 @@ static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_e
     DevBuffers& d = c->d;
     const int B = d.B;
     hipStream_t s = c->stream;
-    d.co_resident = lk_gated(c) ? 1 : 0;                              // picks the 96-register builds of the f64 kernels (svo_kernels_pnp.hip)
+    static const bool force_lean = getenv("SVO_FORCE_LEAN") && atoi(getenv("SVO_FORCE_LEAN")) != 0;      // test knob: every context takes them
+    d.co_resident = (lk_gated(c) || force_lean) ? 1 : 0;               // picks the 96-register builds of the f64 kernels (svo_kernels_pnp.hip)
     const uint8_t** dp = d.img_ptrs + (size_t)slot * 2 * B;         // the slot's pointer table: pinned host memory the kernel reads in place
     launch_ingest_pyramid(d, dp, stride, s, true);                    // + the per-frame reset
     if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
