@@ -197,11 +197,11 @@ void launch_pnp_subsets(const DevBuffers& d, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ EPnP on 5 points
-// 8 lanes cooperate on one hypothesis (8 hypotheses per 64-thread block); every array lives in an LDS arena
-// (no scratch memory).  The 12x12 one-sided Jacobi SVD of MtM — 85 % of EPnP's work — sweeps its row pairs in
-// round-robin order: the 6 pairs of a round are disjoint, so lanes 0..5 rotate them in parallel and the result is
-// bit-identical to the sequential round-robin loop.  The three beta approximations (N = 4, 2, 3 null vectors) are
-// independent after L and rho and run on lanes 0..2.
+// 8 or 32 lanes cooperate on one hypothesis (8 or 2 hypotheses per 64-thread block); the matrices live in an LDS arena.
+// The 12x12 one-sided Jacobi SVD of MtM — more than half of EPnP's time — sweeps its row pairs in round-robin order: the 6
+// pairs of a round are disjoint, so they rotate in parallel (one lane per pair, or four: rotate_pair12_quads) and the result is
+// bit-identical to the sequential round-robin loop.  The three beta approximations (N = 4, 2, 3 null vectors) are independent
+// after L and rho and run on lanes 0..2.
 #define EP_G 8                                   // lanes per hypothesis, many sequences (k_pnp_epnp_lean); 64 / EP_G hypotheses per block
 #define EP_LEAN_LDS ((64 / EP_G) * EP_STRIDE * sizeof(double))
 #define EP_G_LONE 32                             // lanes per hypothesis when few sequences run (k_pnp_epnp): see rotate_pair12_quads
