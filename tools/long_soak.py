@@ -3,7 +3,8 @@ side; every frame's flags, counters and feature set must match bit for bit.  usa
 Round-1 results on an MI355X box: 200 frames, step 0.08 m: 0 mismatching frames, 199 poses, max |dt| 1.1e-9 m, ATE 5.2 cm over
 15.9 m vs ground truth, 5.5e-10 m vs the oracle; step 0.5 m (the camera flies out of the rendered scene after ~40 frames, so most
 frames take the failure paths): 0 mismatching frames as well.
-Round 2, with the independently moving layer (movers 0.3, step 0.08): see DESIGN.md §4."""
+Round 2, with the independently moving layer (movers 0.3, step 0.08), final build: 200 frames, 0 mismatching frames, 198 poses,
+max |dt| 1.8e-9 m, ATE 4.1 cm over 15.9 m vs ground truth, 8e-10 m vs the oracle."""
 import sys, os, time, numpy as np
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,ROOT+'/tests')
 import oracle_lib as orc
