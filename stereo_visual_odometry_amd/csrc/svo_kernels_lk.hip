@@ -757,14 +757,14 @@ static int lk_xcd_mapping() { static int v = -1; if (v < 0) { const char* e = ge
 // winSize is a mutable member in the reference (vo.h:251), so every square window from 5 to 31 is built: the tuned entries
 // first (lanes per feature chosen by measurement), then the generic one-wave-per-feature form for all other sizes — the same
 // code (LkLayout derives the segment shape from W), just not tuned.
-#define LK_FOR_EACH_WINDOW_TUNED(X) X(7, 16) X(10, 16) X(15, 32) X(15, 64) X(21, 64) X(21, 32) X(31, 64)
+#define LK_FOR_EACH_WINDOW_TUNED(X) X(7, 16) X(7, 64) X(10, 16) X(10, 64) X(15, 32) X(15, 64) X(21, 64) X(21, 32) X(31, 64)
 #define LK_FOR_EACH_WINDOW_GENERIC(X) X(5, 64) X(6, 64) X(8, 64) X(9, 64) X(11, 64) X(12, 64) X(13, 64) X(14, 64) X(16, 64) X(17, 64) X(18, 64) \
     X(19, 64) X(20, 64) X(22, 64) X(23, 64) X(24, 64) X(25, 64) X(26, 64) X(27, 64) X(28, 64) X(29, 64) X(30, 64)
 #define LK_FOR_EACH_WINDOW(X) LK_FOR_EACH_WINDOW_TUNED(X) LK_FOR_EACH_WINDOW_GENERIC(X)
 
 // 3-channel (BGR) instantiations: one per window up to 21, at the window's default lanes-per-feature (beyond that a lane would
 // hold three planes of >= 11 pixels of template and search window: more registers than a wave has)
-#define LK_FOR_EACH_WINDOW_CN3(X) X(7, 16) X(10, 16) X(15, 32) X(21, 64) X(5, 64) X(6, 64) X(8, 64) X(9, 64) X(11, 64) X(12, 64) X(13, 64) \
+#define LK_FOR_EACH_WINDOW_CN3(X) X(7, 16) X(7, 64) X(10, 16) X(10, 64) X(15, 32) X(15, 64) X(21, 64) X(5, 64) X(6, 64) X(8, 64) X(9, 64) X(11, 64) X(12, 64) X(13, 64) \
     X(14, 64) X(16, 64) X(17, 64) X(18, 64) X(19, 64) X(20, 64)
 
 // Smallest float x with (double)(float)(x / (2 w^2)) >= threshold — found by bisection over the floats in their numeric order
@@ -793,20 +793,23 @@ bool lk_window_supported_cn(int win, int cn) {
 #undef CHK
     return false;
 }
-static int lk_group_for(int win) {
+// lone: a context of a few sequences (latency matters, the GPU is far from full): one feature per wave whatever the window —
+// a wave that carries four features (w = 7, 10) or two (w = 15) runs until its slowest one is done and does 4x / 2x the work
+// per Newton step in one instruction stream; measured on the reference's run1 set (512 x 288, w = 10, ~100-400 features).
+static int lk_group_for(int win, bool lone) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("SVO_LK_G"); env = e ? atoi(e) : 0; }
-    int def = 0; bool have_env = false;
-#define CHK(Wn, Gn) if (win == Wn) { if (!def) def = Gn; if (env == Gn) have_env = true; }
+    int def = 0; bool have_env = false, have64 = false;
+#define CHK(Wn, Gn) if (win == Wn) { if (!def) def = Gn; if (env == Gn) have_env = true; if (Gn == 64) have64 = true; }
     LK_FOR_EACH_WINDOW(CHK)
 #undef CHK
-    return have_env ? env : def;
+    return have_env ? env : (lone && have64) ? 64 : def;
 }
 
 void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
     if (grid_n < 1) grid_n = 1;
     if (grid_n > d.CAP) grid_n = d.CAP;
-    const int G = lk_group_for(d.cfg.win_w);
+    const int G = lk_group_for(d.cfg.win_w, d.B <= SVO_LONE_MAX_SEQ);
     const int mode = lk_xcd_mapping();
 #define LAUNCH(Wn, Gn) if (d.cfg.win_w == Wn && G == Gn) { int gx = (grid_n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
         const int chunk = lk_chunk(); \
@@ -819,8 +822,8 @@ void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
     if (d.CN == 1) { LK_FOR_EACH_WINDOW(LAUNCH) }
 #undef CNn
 #undef LAUNCH
-    // 3-channel contexts: the window's default group size only
-#define LAUNCH3(Wn, Gn) if (d.cfg.win_w == Wn) { int gx = (grid_n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
+    // 3-channel contexts
+#define LAUNCH3(Wn, Gn) if (d.cfg.win_w == Wn && G == Gn) { int gx = (grid_n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
         const int chunk = lk_chunk(); \
         gx = (gx + 8 * chunk - 1) / (8 * chunk) * (8 * chunk); \
         const int rounds = (d.B + 7) / 8; \
@@ -834,7 +837,7 @@ void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
 void launch_lk_single(const DevBuffers& d, int slotA, int camA, int slotB, int camB, int n, const float2* prev, float2* next,
                       uint8_t* status, hipStream_t st) {
     if (n <= 0) return;
-    const int G = lk_group_for(d.cfg.win_w);
+    const int G = lk_group_for(d.cfg.win_w, d.B <= SVO_LONE_MAX_SEQ);
 #define LAUNCH(Wn, Gn) if (d.cfg.win_w == Wn && G == Gn) { int gx = (n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
         hipLaunchKernelGGL((k_lk_single<Wn, Gn>), dim3(gx), dim3(64), 0, st, d, slotA, camA, slotB, camB, n, prev, next, status); return; }
     LK_FOR_EACH_WINDOW(LAUNCH)

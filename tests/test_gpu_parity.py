@@ -648,6 +648,41 @@ def test_two_many_sequence_contexts_sharing_the_device(api):
     assert seen_iters > 3                                           # the adaptive loop really ran
 
 
+@pytest.mark.parametrize("win", [7, 10, 15])
+def test_many_sequence_context_small_windows(api, win):
+    """Windows 7 / 10 / 15 have two LK builds: one feature per wave for contexts of a few sequences (latency) and four / four /
+    two features per wave for many-sequence contexts (throughput).  The single-stream tests run the first; this one runs the
+    second (9 sequences in one context) against the oracle."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=400, height=176, cx=200.0, cy=88.0)
+    over = dict(win_w=win, win_h=win, max_level=2, max_translation_norm=2.0)
+    seqs = [syn.StereoSequence(cal=cal, n_frames=3, seed=300 + 7 * win + s, step=0.3) for s in range(2)]
+    Pl, Pr = syn.projection_matrices(cal)
+    want = []
+    for sq in seqs:
+        o = orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl, Pr)
+        per = []
+        for k in range(3):
+            ok, T = o.stereo_callback(sq.left[k], sq.right[k])
+            per.append((ok, T.copy(), {f[0]: getattr(o.stats, f[0]) for f in o.stats._fields_}, [a.copy() for a in o.features()], o.last_tracks() if k else None))
+        want.append(per)
+    B = 9
+    vo = api.BatchVisualOdometry(400, 176, B, api.default_config(**over)); vo.initalize_projection_matricies(Pl, Pr)
+    for k in range(3):
+        ok, T = vo.stereo_callback_batch([seqs[i % 2].left[k] for i in range(B)], [seqs[i % 2].right[k] for i in range(B)])
+        for i in range(B):
+            w = want[i % 2][k]
+            assert bool(ok[i]) == w[0] and vo.stats[i].as_dict() == w[2], (k, i, vo.stats[i].as_dict(), w[2])
+            assert np.abs(T[i][:3, 3] - w[1][:3, 3]).max() < POSE_TOL_T
+        for i in (0, B - 1):
+            f = vo.features(i); w = want[i % 2][k]
+            assert np.array_equal(bits(f[0]), bits(w[3][0])) and np.array_equal(f[1], w[3][1]) and np.array_equal(f[2], w[3][2])
+            if k:
+                tg = vo.last_tracks(i)
+                for key in ("pl0", "pr0", "pl1", "pr1"):
+                    assert np.array_equal(bits(w[4][key]), bits(tg[key])), (k, i, key)
+
+
 # ---------------------------------------------------------------- the other BASELINE.json configs as parity cases
 def test_max_features_preset_keeps_the_first_n_in_bucket_order(api):
     """The build preset of SURVEY.md 8d cfg2 (not in the reference): only the first max_features of the bucketed set enter
