@@ -793,23 +793,26 @@ bool lk_window_supported_cn(int win, int cn) {
 #undef CHK
     return false;
 }
-// lone: a context of a few sequences (latency matters, the GPU is far from full): one feature per wave whatever the window —
-// a wave that carries four features (w = 7, 10) or two (w = 15) runs until its slowest one is done and does 4x / 2x the work
-// per Newton step in one instruction stream; measured on the reference's run1 set (512 x 288, w = 10, ~100-400 features).
-static int lk_group_for(int win, bool lone) {
+// One feature per wave (64 lanes) is the default for EVERY window.  Round 1 chose four features per wave for w = 7 and 10 and two
+// for w = 15 by measurement; after round 2's work on the kernel (wave-uniform control flow, scalar base addresses, two-value
+// reductions — all of which need the whole wave on one feature) the 64-lane build wins at every batch size, re-measured on
+// KITTI-sized frames with ~2 000 features (LK time per frame, 64 lanes vs grouped): w = 10: 111 vs 239 us at 1 sequence, 285 vs
+// 411 at 8, 1 809 vs 1 954 at 64; w = 15: 135 vs 213, 363 vs 458, 2 375 vs 2 676.  A grouped wave runs until its slowest feature
+// is done and cannot branch per feature.  The grouped builds stay selectable (SVO_LK_G=16 / 32) for measurement.
+static int lk_group_for(int win) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("SVO_LK_G"); env = e ? atoi(e) : 0; }
     int def = 0; bool have_env = false, have64 = false;
 #define CHK(Wn, Gn) if (win == Wn) { if (!def) def = Gn; if (env == Gn) have_env = true; if (Gn == 64) have64 = true; }
     LK_FOR_EACH_WINDOW(CHK)
 #undef CHK
-    return have_env ? env : (lone && have64) ? 64 : def;
+    return have_env ? env : have64 ? 64 : def;
 }
 
 void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
     if (grid_n < 1) grid_n = 1;
     if (grid_n > d.CAP) grid_n = d.CAP;
-    const int G = lk_group_for(d.cfg.win_w, d.B <= SVO_LONE_MAX_SEQ);
+    const int G = lk_group_for(d.cfg.win_w);
     const int mode = lk_xcd_mapping();
 #define LAUNCH(Wn, Gn) if (d.cfg.win_w == Wn && G == Gn) { int gx = (grid_n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
         const int chunk = lk_chunk(); \
@@ -837,7 +840,7 @@ void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
 void launch_lk_single(const DevBuffers& d, int slotA, int camA, int slotB, int camB, int n, const float2* prev, float2* next,
                       uint8_t* status, hipStream_t st) {
     if (n <= 0) return;
-    const int G = lk_group_for(d.cfg.win_w, d.B <= SVO_LONE_MAX_SEQ);
+    const int G = lk_group_for(d.cfg.win_w);
 #define LAUNCH(Wn, Gn) if (d.cfg.win_w == Wn && G == Gn) { int gx = (n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
         hipLaunchKernelGGL((k_lk_single<Wn, Gn>), dim3(gx), dim3(64), 0, st, d, slotA, camA, slotB, camB, n, prev, next, status); return; }
     LK_FOR_EACH_WINDOW(LAUNCH)

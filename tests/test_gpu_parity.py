@@ -650,9 +650,9 @@ def test_two_many_sequence_contexts_sharing_the_device(api):
 
 @pytest.mark.parametrize("win", [7, 10, 15])
 def test_many_sequence_context_small_windows(api, win):
-    """Windows 7 / 10 / 15 have two LK builds: one feature per wave for contexts of a few sequences (latency) and four / four /
-    two features per wave for many-sequence contexts (throughput).  The single-stream tests run the first; this one runs the
-    second (9 sequences in one context) against the oracle."""
+    """A many-sequence context (9 sequences) at the small windows against the oracle.  (These windows also have grouped LK
+    builds — four / four / two features per wave, selectable with SVO_LK_G=16 / 32 for measurement; run this file once with that
+    variable set to put them through the same checks.)"""
     from stereo_visual_odometry_amd import synthetic as syn
     cal = dict(syn.KITTI00, width=400, height=176, cx=200.0, cy=88.0)
     over = dict(win_w=win, win_h=win, max_level=2, max_translation_norm=2.0)
