@@ -126,5 +126,6 @@ void launch_lk_single(const DevBuffers& d, int slotA, int camA, int slotB, int c
                       uint8_t* status, hipStream_t s);
 void launch_find_close(int n, const float2* a, const float2* b, float thr, uint8_t* ok, hipStream_t s);
 bool lk_window_supported(int win);
+int lk_registers_left(const DevBuffers& d);   // VGPRs per SIMD lane beside a full set of this context's LK waves (-1: unknown)
 bool lk_window_supported_cn(int win, int cn);
 float lk_mineig_cut(int win, double min_eig_threshold);

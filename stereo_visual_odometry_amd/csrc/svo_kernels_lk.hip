@@ -809,6 +809,27 @@ static int lk_group_for(int win) {
     return have_env ? env : have64 ? 64 : def;
 }
 
+// VGPRs a SIMD has left beside a full complement of this context's LK waves (512 per SIMD lane, allocated in eights, at most 8
+// waves): the 96-register builds of the f64 kernels (svo_kernels_pnp.hip) can run under another context's LK grid only if this
+// is >= 96 — true at w = 21 (100 registers: four waves, 96 left) and 31, not at w = 10 (74: six waves, 32 left).  -1 if unknown.
+int lk_registers_left(const DevBuffers& d) {
+    const int G = lk_group_for(d.cfg.win_w);
+    const void* fn = nullptr;
+#define PICK(Wn, Gn) if (!fn && d.cfg.win_w == Wn && G == Gn) fn = (const void*)k_lk_chain<Wn, Gn, CNn>;
+#define CNn 1
+    if (d.CN == 1) { LK_FOR_EACH_WINDOW(PICK) }
+#undef CNn
+#define CNn 3
+    if (d.CN == 3) { LK_FOR_EACH_WINDOW_CN3(PICK) }
+#undef CNn
+#undef PICK
+    hipFuncAttributes at;
+    if (!fn || hipFuncGetAttributes(&at, fn) != hipSuccess || at.numRegs <= 0) return -1;
+    const int alloc = (at.numRegs + 7) / 8 * 8;
+    int waves = 512 / alloc; if (waves > 8) waves = 8;
+    return 512 - waves * alloc;
+}
+
 void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
     if (grid_n < 1) grid_n = 1;
     if (grid_n > d.CAP) grid_n = d.CAP;
