@@ -2,6 +2,7 @@
  * one-sided Jacobi SVD (the method OpenCV's cv::SVD uses for small matrices when built without
  * LAPACK, modules/core/src/lapack.cpp JacobiSVDImpl_), SVD back-substitution, least squares.
  * Only + - * / sqrt are used, in a fixed order, so the HIP kernels can reproduce the bits. */
+#include "orc.h"
 #include "orc_linalg.h"
 #include <float.h>
 #include <math.h>
@@ -16,7 +17,9 @@ static int rotate_pair(double* At, int m, int n, double* W, double* Vt, int i, i
     for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
     if (fabs(p) <= eps * sqrt(a * b)) return 0;
     p *= 2;
-    double beta = a - b, gamma = sqrt(p * p + beta * beta);
+    /* JacobiSVDImpl_ calls hypot(p, beta) (libm); the oracle's default is the plain sqrt form the HIP kernels reproduce bit
+       for bit — ORC_OCV_HYPOT (a deviation switch, orc.h) selects libm's */
+    double beta = a - b, gamma = (orc_get_opencv_mode() & ORC_OCV_HYPOT) ? hypot(p, beta) : sqrt(p * p + beta * beta);
     if (beta < 0) {
         double delta = (gamma - beta) * 0.5;
         s = sqrt(delta / gamma);

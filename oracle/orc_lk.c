@@ -128,6 +128,73 @@ long long orc_lk_counters[4] = {0, 0, 0, 0};
 #define W_BITS 14
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
+/* ---- deviation switches (orc.h) ---- */
+static unsigned g_ocv_mode = 0;
+unsigned orc_set_opencv_mode(unsigned mask) { unsigned old = g_ocv_mode; g_ocv_mode = mask; return old; }
+unsigned orc_get_opencv_mode(void) { return g_ocv_mode; }
+
+/* D1 reverted: the sums of LKTrackerInvoker in FLOAT, in the order OpenCV 4.5's lkpyramid.cpp produces on x86
+ * (`#if CV_SIMD128 && !CV_NEON`, acctype = itemtype = float).  A window row is E = w*cn interleaved elements
+ * (element e = pixel e/cn, channel e%cn).  Patches are stored per plane: element e of row y is [(c*wh + y)*ww + px].
+ *   A:  `for (; x <= E - 8; x += 8)`: elements x..x+3 then x+4..x+7 go to float lanes 0..3 of qA11/qA12/qA22 by
+ *       v_muladd(fx, fy, q) (unfused at an SSE baseline); the scalar tail adds (float)(ix*iy) to iA; after the rows
+ *       iA += v_reduce_sum(q) = (q0 + q2) + (q1 + q3).
+ *   b:  per 8 elements v_dotprod pairs element k with k+4 in int32, v_cvt_f32, added to qb0 (k = 0, 1) / qb1 (k = 2, 3),
+ *       lanes (bx, by, bx, by); at the end s = qb0 + qb1, ib1 += s0 + s2, ib2 += s1 + s3.
+ * Variants (orc.h): FMA, the 3.x SSE2 form (A in steps of 4, reduce ((q0+q1)+q2)+q3), no SIMD. */
+static inline float mul_add_f(float a, float b, float c, int fma) { return fma ? fmaf(a, b, c) : a * b + c; }
+
+static void d1_sum_A(unsigned mode, int cn, int ww, int wh, const int16_t* dIw, float* A11, float* A12, float* A22) {
+    const int E = ww * cn, fma = (mode & ORC_OCV_D1_FMA) != 0;
+    const int step = (mode & ORC_OCV_D1_SCALAR) ? 0 : (mode & ORC_OCV_D1_W4) ? 4 : 8;
+    const int nsimd = step ? (E / step) * step : 0;
+    float q11[4] = {0, 0, 0, 0}, q12[4] = {0, 0, 0, 0}, q22[4] = {0, 0, 0, 0}, t11 = 0, t12 = 0, t22 = 0;
+    int y, e;
+    for (y = 0; y < wh; y++)
+        for (e = 0; e < E; e++) {
+            const int16_t* d = dIw + ((size_t)((e % cn) * wh + y) * ww + e / cn) * 2;
+            int ix = d[0], iy = d[1];
+            if (e < nsimd) {
+                float fx = (float)ix, fy = (float)iy; int L = e & 3;
+                q22[L] = mul_add_f(fy, fy, q22[L], fma); q12[L] = mul_add_f(fx, fy, q12[L], fma); q11[L] = mul_add_f(fx, fx, q11[L], fma);
+            } else { t11 += (float)(ix * ix); t12 += (float)(ix * iy); t22 += (float)(iy * iy); }
+        }
+    if (mode & ORC_OCV_D1_W4) {
+        t11 += q11[0] + q11[1] + q11[2] + q11[3]; t12 += q12[0] + q12[1] + q12[2] + q12[3]; t22 += q22[0] + q22[1] + q22[2] + q22[3];
+    } else {
+        t11 += (q11[0] + q11[2]) + (q11[1] + q11[3]); t12 += (q12[0] + q12[2]) + (q12[1] + q12[3]); t22 += (q22[0] + q22[2]) + (q22[1] + q22[3]);
+    }
+    *A11 = t11; *A12 = t12; *A22 = t22;
+}
+
+static void d1_sum_b(unsigned mode, int cn, int ww, int wh, const int16_t* dIw, const int16_t* diffw, float* b1, float* b2) {
+    const int E = ww * cn;
+    const int nsimd = (mode & ORC_OCV_D1_SCALAR) ? 0 : (E / 8) * 8;
+    float qb0[4] = {0, 0, 0, 0}, qb1[4] = {0, 0, 0, 0}, t1 = 0, t2 = 0;
+    int y, e, k;
+    for (y = 0; y < wh; y++) {
+        int it[8], ix[8], iy[8];
+        for (e = 0; e < E; e++) {
+            size_t at = (size_t)((e % cn) * wh + y) * ww + e / cn;
+            int dv = diffw[at], dx = dIw[2 * at], dy = dIw[2 * at + 1];
+            if (e < nsimd) {
+                k = e & 7; it[k] = dv; ix[k] = dx; iy[k] = dy;
+                if (k == 7) {
+                    qb0[0] += (float)(it[0] * ix[0] + it[4] * ix[4]); qb0[1] += (float)(it[0] * iy[0] + it[4] * iy[4]);
+                    qb0[2] += (float)(it[1] * ix[1] + it[5] * ix[5]); qb0[3] += (float)(it[1] * iy[1] + it[5] * iy[5]);
+                    qb1[0] += (float)(it[2] * ix[2] + it[6] * ix[6]); qb1[1] += (float)(it[2] * iy[2] + it[6] * iy[6]);
+                    qb1[2] += (float)(it[3] * ix[3] + it[7] * ix[7]); qb1[3] += (float)(it[3] * iy[3] + it[7] * iy[7]);
+                }
+            } else { t1 += (float)(dv * dx); t2 += (float)(dv * dy); }
+        }
+    }
+    {
+        float s0 = qb0[0] + qb1[0], s1 = qb0[1] + qb1[1], s2 = qb0[2] + qb1[2], s3 = qb0[3] + qb1[3];
+        t1 += s0 + s2; t2 += s1 + s3;
+    }
+    *b1 = t1; *b2 = t2;
+}
+
 static inline int cv_round_f(float v) { return (int)lrintf(v); }     /* round-half-even under the default mode */
 static inline int cv_floor_f(float v) { return (int)floorf(v); }
 
@@ -149,8 +216,10 @@ static void lk_level(int cn, const orc_pyramid* const* Apl, const orc_pyramid* c
 #pragma omp parallel
     {
     long long cnt_visit = 0, cnt_step = 0, cnt_all = 0;                  /* per-thread, added to the globals once below */
-    int16_t* Iw = (int16_t*)malloc(sizeof(int16_t) * (size_t)ww * wh * 3 * cn);
+    int16_t* Iw = (int16_t*)malloc(sizeof(int16_t) * (size_t)ww * wh * 4 * cn);
     int16_t* dIw = Iw + (size_t)ww * wh * cn;
+    int16_t* diffw = Iw + (size_t)ww * wh * cn * 3;       /* mismatch patch, used by the D1-reverted float sums only */
+    const unsigned ocv = g_ocv_mode;
     int x, y, j, pc;
 #pragma omp for schedule(dynamic, 16)
     for (i = 0; i < n; i++) {
@@ -189,6 +258,10 @@ static void lk_level(int cn, const orc_pyramid* const* Apl, const orc_pyramid* c
         }
         /* |sum| < 2^53: int64 -> double is exact, double -> float rounds once (nearest-even) */
         float A11 = (float)(double)iA11 * FLT_SCALE, A12 = (float)(double)iA12 * FLT_SCALE, A22 = (float)(double)iA22 * FLT_SCALE;
+        if (ocv & ORC_OCV_D1_LK_FLOAT) {
+            d1_sum_A(ocv, cn, ww, wh, dIw, &A11, &A12, &A22);
+            A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
+        }
         float D = A11 * A22 - A12 * A12;
         float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww * wh);
         if ((double)minEig < min_eig_threshold || D < 1.1920928955078125e-07f /* FLT_EPSILON */) {
@@ -220,9 +293,14 @@ static void lk_level(int cn, const orc_pyramid* const* Apl, const orc_pyramid* c
                 for (x = 0; x < ww; x++, dp += 2) {
                     int diff = DESCALE(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stepJ] * iw10 + Jp[x + stepJ + 1] * iw11, W_BITS - 5) - Ip[x];
                     ib1 += (int64_t)(diff * dp[0]); ib2 += (int64_t)(diff * dp[1]);
+                    diffw[(size_t)(pc * wh + y) * ww + x] = (int16_t)diff;
                 }
             }
             float b1 = (float)(double)ib1 * FLT_SCALE, b2 = (float)(double)ib2 * FLT_SCALE;
+            if (ocv & ORC_OCV_D1_LK_FLOAT) {
+                d1_sum_b(ocv, cn, ww, wh, dIw, diffw, &b1, &b2);
+                b1 *= FLT_SCALE; b2 *= FLT_SCALE;
+            }
             float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
             npx += dx; npy += dy;
             next_pts[2 * i] = npx + half_x; next_pts[2 * i + 1] = npy + half_y;

@@ -2,7 +2,7 @@
  * Stands in for cv::triangulatePoints + cv::convertPointsFromHomogeneous (/root/reference/src/vo.cpp:89-94),
  * cv::solvePnPRansac + cv::Rodrigues (vo.cpp:282-313) and the 4x4 inverse of vo.cpp:246-258, restating
  * OpenCV 4.5 modules/calib3d/src/{triangulate,solvepnp,ptsetreg,epnp,calibration}.cpp and
- * modules/core/src/rand.cpp as summarised in SURVEY.md Appendix A.4-A.7.  Deviations D2-D4: orc.h. */
+ * modules/core/src/rand.cpp as summarised in SURVEY.md Appendix A.4-A.7.  Deviations D2, D4, D5: orc.h. */
 #include "orc.h"
 #include "orc_linalg.h"
 #include <float.h>
@@ -271,12 +271,20 @@ double orc_epnp(int n, const double* obj, const double* img, double fx, double f
        cyclic-by-rows order; the ordering is not observable through any reference test and the parallel order is the
        one the GPU kernel can run with 6 lanes per hypothesis, bit-identically (deviation D5 in orc.h). */
     memcpy(Ut, MtM, sizeof(MtM));
-    orc_jacobi_svd_ord(Ut, 12, 12, W, Vt, 0, 1);
-    /* L_6x10 and rho; null-space basis v[i] = Vt row 11-i (deviation D3) */
+    /* The basis EPnP reads is the LEFT singular vectors — the normalised rows of the rotated At — as
+       cvSVD(&MtM, &D, &Ut, 0, CV_SVD_MODIFY_A | CV_SVD_U_T) returns them (epnp.cpp).  Rounds 1-2 read the right ones (former
+       deviation D3): same subspace, but for the two (numerically) zero singular values of a 5-point MtM a different basis OF it,
+       and the beta approximations depend on the basis — measured on the reference's recording (tools/deviation_ablation.py):
+       with the left vectors all 128 rows of run1/result.csv are reproduced, with the right ones an inlier decision flips at
+       frame 25.  Deviation switches (orc.h): ORC_ALT_D3_RIGHT puts the old behaviour back; D5 reverted = cyclic-by-rows sweeps. */
+    const unsigned ocv = orc_get_opencv_mode();
+    orc_jacobi_svd_ord(Ut, 12, 12, W, Vt, 12, (ocv & ORC_OCV_D5_JACOBI_CYCLIC) ? 0 : 1);
+    const double* basis = (ocv & ORC_ALT_D3_RIGHT) ? Vt : Ut;
+    /* L_6x10 and rho; null-space basis v[i] = basis row 11-i */
     double L[60], rho[6];
     {
         const double* v[4]; double dv[4][6][3];
-        for (i = 0; i < 4; i++) v[i] = Vt + 12 * (11 - i);
+        for (i = 0; i < 4; i++) v[i] = basis + 12 * (11 - i);
         for (i = 0; i < 4; i++) {
             int a = 0, b = 1;
             for (j = 0; j < 6; j++) {
@@ -310,7 +318,7 @@ double orc_epnp(int n, const double* obj, const double* img, double fx, double f
         if (b4[0] < 0) { be[0] = sqrt(-b4[0]); be[1] = -b4[1] / be[0]; be[2] = -b4[2] / be[0]; be[3] = -b4[3] / be[0]; }
         else { be[0] = sqrt(b4[0]); be[1] = b4[1] / be[0]; be[2] = b4[2] / be[0]; be[3] = b4[3] / be[0]; }
         epnp_gauss_newton(L, rho, be);
-        rep[1] = epnp_compute_R_and_t(&e, Vt, be, Rs[1], ts[1]);
+        rep[1] = epnp_compute_R_and_t(&e, basis, be, Rs[1], ts[1]);
     }
     {   /* approx 2: [B11 B12 B22] from columns {0,1,2} */
         double L3[18], b3[3];
@@ -322,7 +330,7 @@ double orc_epnp(int n, const double* obj, const double* img, double fx, double f
         if (b3[1] < 0) be[0] = -be[0];
         be[2] = 0.0; be[3] = 0.0;
         epnp_gauss_newton(L, rho, be);
-        rep[2] = epnp_compute_R_and_t(&e, Vt, be, Rs[2], ts[2]);
+        rep[2] = epnp_compute_R_and_t(&e, basis, be, Rs[2], ts[2]);
     }
     {   /* approx 3: [B11 B12 B22 B13 B23] from columns {0..4} */
         double L5[30], b5[5];
@@ -335,7 +343,7 @@ double orc_epnp(int n, const double* obj, const double* img, double fx, double f
         be[2] = b5[3] / be[0];
         be[3] = 0.0;
         epnp_gauss_newton(L, rho, be);
-        rep[3] = epnp_compute_R_and_t(&e, Vt, be, Rs[3], ts[3]);
+        rep[3] = epnp_compute_R_and_t(&e, basis, be, Rs[3], ts[3]);
     }
     int N = 1;
     if (rep[2] < rep[1]) N = 2;
@@ -476,7 +484,8 @@ int orc_camera_to_world(const float K[9], int n, const float* cam_pts, const flo
                         double R[9], double t[3], int* inliers, int* n_inliers,
                         int ransac_iterations, float reproj_error, float confidence, int* dbg) {
     const int model_points = 5;
-    double bestR[9], bestT[3];
+    const unsigned ocv = orc_get_opencv_mode();
+    double bestR[9], bestT[3], lastR[9], lastT[3];
     int i, iter, max_good = 0, iters_run = 0;
     *n_inliers = 0;
     if (dbg) { dbg[0] = 0; dbg[1] = 0; }
@@ -531,6 +540,11 @@ int orc_camera_to_world(const float K[9], int n, const float* cam_pts, const flo
             }
             double Rm[9], tm[3];
             epnp_on_subset(K, world_pts, cam_pts, idx, 5, Rm, tm);
+            if (ocv & ORC_OCV_D4_RVEC_TRIP) {      /* the model is rvec|tvec (PnPRansacCallback::runKernel); projectPoints rebuilds R from it */
+                double rv[3];
+                orc_rodrigues_to_vector(Rm, rv); orc_rodrigues_to_matrix(rv, Rm, NULL);
+            }
+            memcpy(lastR, Rm, sizeof(lastR)); memcpy(lastT, tm, sizeof(lastT));
             int good = score_model(K, n, world_pts, cam_pts, Rm, tm, thr2, mask);
             iters_run = iter + 1;
             if (good > (max_good > model_points - 1 ? max_good : model_points - 1)) {
@@ -553,6 +567,9 @@ int orc_camera_to_world(const float K[9], int n, const float* cam_pts, const flo
             obj[3 * m] = world_pts[3 * i]; obj[3 * m + 1] = world_pts[3 * i + 1]; obj[3 * m + 2] = world_pts[3 * i + 2];
             img[2 * m] = cam_pts[2 * i]; img[2 * m + 1] = cam_pts[2 * i + 1];
             inliers[m] = i; m++;
+        }
+        if (ocv & ORC_OCV_D2_LM_FROM_LAST) {   /* rvec / tvec alias the callback's buffers: they hold the LAST hypothesis solved */
+            memcpy(bestR, lastR, sizeof(bestR)); memcpy(bestT, lastT, sizeof(bestT));
         }
         orc_rodrigues_to_vector(bestR, rvec);
         orc_pnp_refine_lm(m, obj, img, fx, fy, cx, cy, rvec, bestT);

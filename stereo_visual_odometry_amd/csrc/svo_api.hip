@@ -736,6 +736,12 @@ extern "C" int svo_append_features_from_image(int device, const svo_config* cfg_
     SeqState hs; memset(&hs, 0, sizeof(hs));
     hs.frame_id = 1; hs.active = 1; hs.slot_img_t0 = 0; hs.slot_pyr_t0 = 0; hs.slot_t1 = 1; hs.n_feat = n; hs.n_old = n; hs.feat_buf = 0;
     rc = set_state(c, hs); if (rc != SVO_OK) return rc;
+    // Only detection pass 0 runs here.  When it keeps fewer than pre_matching_feature_threshold features its last emit block
+    // offers them to the grid for a pass 1 that this entry point never launches, and the cached context would carry those keys
+    // and row counts into the next call (phantom / wrong features): the grid state is cleared per call.
+    HIPCHK(hipMemsetAsync(c->d.bucket_keys, 0, sizeof(unsigned long long) * (size_t)c->d.NB, c->stream));
+    HIPCHK(hipMemsetAsync(c->d.bucket_rowcnt, 0, sizeof(int) * (size_t)c->d.cfg.buckets_along_height, c->stream));
+    HIPCHK(hipMemsetAsync(c->d.emit_ticket, 0, sizeof(int), c->stream));
     launch_detect(c->d, 0, fast_threshold, c->stream);
     HIPCHK(hipGetLastError());
     int m = svo_get_features(c, 0, cap, xy, ages, strengths);

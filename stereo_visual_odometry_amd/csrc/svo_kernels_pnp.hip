@@ -204,11 +204,11 @@ void launch_pnp_subsets(const DevBuffers& d, hipStream_t st) {
 // after L and rho and run on lanes 0..2.
 #define EP_G 8                                   // lanes per hypothesis, many sequences (k_pnp_epnp_lean); 64 / EP_G hypotheses per block
 #define EP_LEAN_LDS ((64 / EP_G) * EP_STRIDE * sizeof(double))
-#define EP_G_LONE 32                             // lanes per hypothesis when few sequences run (k_pnp_epnp): see rotate_pair12_quads
+#define EP_G_LONE 16                             // lanes per hypothesis when few sequences run (k_pnp_epnp): see rotate_pair12_halves
 #define EP_STRIDE 1032                           // doubles per hypothesis (+8 pad: distinct LDS banks per hypothesis)
 // arena map (doubles)
 #define EA_AT 0                                  // 144  MtM, then the rotating rows
-#define EA_VT 144                                // 144
+#define EA_VT 144                                // 144  rows 8..11: the four basis vectors EPnP reads (normalised rows of At, moved here after the sort)
 #define EA_W 288                                 // 12
 #define EA_M 300                                 // 120  (dead after MtM is built)
 #define EA_PWS 420                               // 15
@@ -226,8 +226,10 @@ static __device__ __forceinline__ double dist2(const double* a, const double* b)
     return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
 }
 
-// one Hestenes rotation of rows i < j (12 x 12), Vt rotated alongside; returns true if the pair was rotated
-static __device__ bool rotate_pair12(double* At, double* Wv, double* Vt, int i, int j) {
+// one Hestenes rotation of rows i < j (12 x 12); returns true if the pair was rotated.  Only the rows of At rotate: EPnP reads
+// the LEFT singular vectors (the normalised rows of the rotated At, as cvSVD(&MtM, &D, &Ut, 0, CV_SVD_MODIFY_A | CV_SVD_U_T)
+// returns them, epnp.cpp), so no Vt is accumulated (round 3; measured against the reference's recording)
+static __device__ bool rotate_pair12(double* At, double* Wv, int i, int j) {
     const double eps = SVO_DBL_EPS * 10;
     double* Ai = At + i * 12; double* Aj = At + j * 12;
     double a = Wv[i], p = 0, b = Wv[j], c, s;
@@ -244,12 +246,6 @@ static __device__ bool rotate_pair12(double* At, double* Wv, double* Vt, int i, 
         a += t0 * t0; b += t1 * t1;
     }
     Wv[i] = a; Wv[j] = b;
-    double* Vi = Vt + i * 12; double* Vj = Vt + j * 12;
-    for (int k = 0; k < 12; k++) {
-        double t0 = c * Vi[k] + s * Vj[k];
-        double t1 = -s * Vi[k] + c * Vj[k];
-        Vi[k] = t0; Vj[k] = t1;
-    }
     return true;
 }
 
@@ -261,29 +257,28 @@ template <int CTRL> static __device__ __forceinline__ double dpp_move_f64(double
     return __hiloint2double(hi, lo);
 }
 
-// The rotation of one pair on FOUR lanes (32 lanes per hypothesis), for a lone stream.  Two SIDES: both compute p, c and s from
-// the rows of At (identical bits), then one side rotates the rows of At and sums the new squared norms, the other rotates the rows
-// of Vt — one instruction stream; every read of At for p precedes, in program order, the first write of the rotated rows (the
-// lanes of a pair sit in one wave).  Two HALVES per side: each side's twelve elements are split over neighbouring lanes.
-// A lone wave per SIMD hides no latency and the compiler orders for register pressure, so the order is pinned with
-// sched_barrier: loads, the row-norm square root under them, independent products, then the rotation software-pipelined
-// (products of element k, sums of k-1, squares of k-2, norms of k-3 per step).  Every sum keeps its element order 0..11: the lower half sums its six terms from zero, hands
-// the partial to its neighbour (DPP row_shr:1), which continues with elements 6..11 — bit for bit the sequential sum — and, for
-// p, hands the total back (row_shl:1).  Per lane 6 instead of 12 elements to load, multiply, rotate, square and store; the two
-// hand-overs cost 12 instructions.
-static __device__ bool rotate_pair12_quads(double* At, double* Wv, double* Vt, int i, int j, bool vside, int half) {
+// The rotation of one pair on TWO lanes (16 lanes per hypothesis), for a lone stream: the twelve elements of the two rows are
+// split over neighbouring lanes (two HALVES), one instruction stream; every read of At precedes, in program order, the first
+// write of the rotated rows (the lanes of a pair sit in one wave).  A lone wave per SIMD hides no latency and the compiler orders
+// for register pressure, so the order is pinned with sched_barrier: loads, the row-norm square root under them, independent
+// products, then the rotation software-pipelined (products of element k, sums of k-1, squares of k-2, norms of k-3 per step).
+// Every sum keeps its element order 0..11: the lower half sums its six terms from zero, hands the partial to its neighbour
+// (DPP row_shr:1), which continues with elements 6..11 — bit for bit the sequential sum — and, for p, hands the total back
+// (row_shl:1).  (Round 2 ran four lanes per pair: a second SIDE rotated the rows of Vt; EPnP reads the left singular vectors
+// since round 3, so that side is gone.)
+static __device__ bool rotate_pair12_halves(double* At, double* Wv, int i, int j, int half) {
     const double eps = SVO_DBL_EPS * 10;
     const int oi = __mul24(i, 12) + half * 6, oj = __mul24(j, 12) + half * 6;
-    const double* Ai = At + oi; const double* Aj = At + oj;
+    double* X = At + oi; double* Y = At + oj;
     double a = Wv[i], b = Wv[j], c, s;
-    double ai[6], aj[6], pr[6];
+    double x[6], y[6], pr[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) { ai[k] = Ai[k]; aj[k] = Aj[k]; }
+    for (int k = 0; k < 6; k++) { x[k] = X[k]; y[k] = Y[k]; }
     __builtin_amdgcn_sched_barrier(0);
     const double lim = eps * sqrt(a * b);                             // while the rows arrive from LDS
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 6; k++) pr[k] = ai[k] * aj[k];
+    for (int k = 0; k < 6; k++) pr[k] = x[k] * y[k];
     __builtin_amdgcn_sched_barrier(0);
     double plo = 0;
 #pragma unroll
@@ -297,10 +292,6 @@ static __device__ bool rotate_pair12_quads(double* At, double* Wv, double* Vt, i
     p *= 2;
     double beta = a - b, gamma = sqrt(p * p + beta * beta);
     jacobi_cs(p, beta, gamma, c, s);
-    double* X = (vside ? Vt : At) + oi; double* Y = (vside ? Vt : At) + oj;
-    double x[6], y[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) { x[k] = X[k]; y[k] = Y[k]; }
     double ma[6], mb[6], mc[6], md[6], t0[6], t1[6], q0[6], q1[6];
     double alo = 0, blo = 0;
     __builtin_amdgcn_sched_barrier(0);
@@ -318,7 +309,7 @@ static __device__ bool rotate_pair12_quads(double* At, double* Wv, double* Vt, i
     double aup = dpp_move_f64<0x111>(alo), bup = dpp_move_f64<0x111>(blo);
 #pragma unroll
     for (int k = 0; k < 6; k++) { aup += q0[k]; bup += q1[k]; }
-    double* Wo = (vside || !half) ? At + EA_M : Wv;                   // the upper At lane holds the norms; the others drop theirs in dead space
+    double* Wo = half ? Wv : At + EA_M;                               // the upper lane holds the norms; the lower drops its partial in dead space
     Wo[i] = aup; Wo[j] = bup;
     return true;
 }
@@ -486,7 +477,7 @@ static __device__ double epnp_compute_R_and_t(const double* ar, const double* be
     return sum2 / n;
 }
 
-// phase 1 (one lane): control points, barycentric coordinates, M, MtM -> arena; W = squared row norms, Vt = I
+// phase 1 (one lane): control points, barycentric coordinates, M, MtM -> arena; W = squared row norms
 static __device__ __attribute__((always_inline)) void epnp_setup(double* ar, double fu, double fv, double uc, double vc) {
     const int n = 5;
     double* pws = ar + EA_PWS; double* us = ar + EA_US; double* alphas = ar + EA_AL; double* cws = ar + EA_CWS;
@@ -531,9 +522,9 @@ static __device__ __attribute__((always_inline)) void epnp_setup(double* ar, dou
 
 // phase 1b (one lane per row i): row i of MtM = M^T M (each entry summed over the 10 rows of M in order; the products commute, so
 // entry (i, j) and entry (j, i) are the same bits: MtM is exactly symmetric, i.e. its own transpose, and the one-sided Jacobi
-// runs in place on it), its squared norm, and row i of Vt = I.
+// runs in place on it) and its squared norm.
 static __device__ void epnp_setup_row(double* ar, int i) {
-    const double* M = ar + EA_M; double* MtM = ar + EA_AT; double* Vt = ar + EA_VT; double* Wv = ar + EA_W;
+    const double* M = ar + EA_M; double* MtM = ar + EA_AT; double* Wv = ar + EA_W;
     double mi[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) mi[k] = M[12 * k + i];
@@ -545,7 +536,6 @@ static __device__ void epnp_setup_row(double* ar, int i) {
         for (int k = 0; k < 10; k++) s += M[12 * k + j] * mi[k];
         MtM[12 * i + j] = s;
         sd += s * s;
-        Vt[i * 12 + j] = i == j ? 1.0 : 0.0;
     }
     Wv[i] = sd;
 }
@@ -553,7 +543,8 @@ static __device__ void epnp_setup_row(double* ar, int i) {
 // phase 3, spread over the lanes of the hypothesis (the caller separates the steps with barriers):
 //   a (lane per row)   singular values = row norms of the rotated MtM
 //   b (one lane)       the descending selection sort (the FIRST maximum wins ties), on (value, row) pairs
-//   c (lanes 0..3)     the four rows of Vt everything after this reads — the sorted rows 11, 10, 9, 8 — move into place
+//   c (lanes 0..3)     the four left singular vectors everything after this reads — the sorted rows 11, 10, 9, 8 of At times
+//                      1 / singular value (JacobiSVDImpl_'s final normalisation) — move to rows 11..8 of the EA_VT block
 //   d (lanes 0..3)     differences of the control points of null vector i;   e (lanes 0..5 + one) L (6x10) row by row, rho
 static __device__ void epnp_row_norm(double* ar, int i) {
     const double* At = ar + EA_AT;
@@ -650,7 +641,7 @@ static __device__ __attribute__((always_inline)) void epnp_branch(double* ar, in
 
 // Hypotheses [h0, h1).  The first chunk (h0 == 0) is always solved; later chunks only up to s.pnp_need, the bound the
 // adaptive loop had reached after the first chunk (the bound only ever shrinks, so nothing beyond it can be consulted).
-template <int G>                          // lanes per hypothesis: 8 (six rotate a pair each, At and Vt) or 16 (twelve: At and Vt on separate lanes)
+template <int G>                          // lanes per hypothesis: 8 (six rotate a pair each) or 16 (twelve: two lanes per pair)
 static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0, int h1, double* arena) {
     constexpr int HPB = 64 / G;
     const int seq = blockIdx.y;
@@ -683,7 +674,7 @@ static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0
     __syncthreads();
     // ---- 12 x 12 one-sided Jacobi, round-robin ordering: lane q < 6 owns pair q of every round
     bool done = !valid;
-    const int qp = G == 32 ? ((q & 15) >> 1) : q;                       // the pair of the round this lane works on
+    const int qp = G == 16 ? (q >> 1) : q;                              // the pair of the round this lane works on (G = 16: lanes 12..15 idle)
     // round r pairs row pa = 1 + (qp - 1 + r) % 11 (row 0 for pair 0) with row pb = 1 + (10 - qp + r) % 11: both walk the
     // cycle 1..11 one step per round and are back where they started after the 11 rounds of a sweep
     int pa = qp, pb = 11 - qp;
@@ -694,8 +685,8 @@ static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0
             pa = qp == 0 ? 0 : pa == 11 ? 1 : pa + 1;
             pb = pb == 11 ? 1 : pb + 1;
             if (!done && qp < 6) {
-                if (G == 32) changed |= rotate_pair12_quads(ar + EA_AT, ar + EA_W, ar + EA_VT, i, j, q >= 16, q & 1);
-                else changed |= rotate_pair12(ar + EA_AT, ar + EA_W, ar + EA_VT, i, j);
+                if (G == 16) changed |= rotate_pair12_halves(ar + EA_AT, ar + EA_W, i, j, q & 1);
+                else changed |= rotate_pair12(ar + EA_AT, ar + EA_W, i, j);
             }
             __syncthreads();
         }
@@ -711,9 +702,13 @@ static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0
     {
         double row[12];
         const bool mover = valid && q < 4;
-        if (mover) { const double* sp = ar + EA_VT + 12 * ((const int*)(ar + EA_M))[q];
+        if (mover) {
+            const int r = ((const int*)(ar + EA_M))[q];
+            const double* sp = ar + EA_AT + 12 * r;
+            const double sd = ar[EA_W + r];
+            const double sc = sd > SVO_DBL_MIN ? 1 / sd : 0.;           // lapack.cpp JacobiSVDImpl_: s = sd > minval ? 1/sd : 0
 #pragma unroll
-            for (int k = 0; k < 12; k++) row[k] = sp[k]; }
+            for (int k = 0; k < 12; k++) row[k] = sp[k] * sc; }
         __syncthreads();
         if (mover) { double* dp = ar + EA_VT + 12 * (11 - q);
 #pragma unroll

@@ -156,6 +156,34 @@ def test_append_features_fused_parity(api, name, th):
     assert np.array_equal(bits(fs.points), bits(want[0])) and np.array_equal(fs.ages, want[1]) and np.array_equal(fs.strengths, want[2])
 
 
+def test_append_features_twice_on_sparse_images_same_thread(api):
+    """Two calls on one thread, same image size, each image yielding fewer than PRE_MATCHING_FEATURE_THRESHOLD (100) features:
+    the cached stage context's first pass offers its survivors for a second pass that this entry point never runs — the grid
+    state it leaves behind must not leak into the next call (round-2 advisor finding: phantom / wrong features)."""
+    from scenes import make_empty_image, add_triangle
+    imgs = []
+    for dx in (0, 37):
+        im = make_empty_image(300, 200)                              # 300 rows x 200 columns
+        for k in range(6):
+            add_triangle(im, 30 + dx + 20 * k, 40 + 40 * k, 8)
+        imgs.append(im)
+    for rep in range(2):
+        for im in imgs:
+            xy, resp = orc.fast_detect(im, 20)
+            assert 0 < len(xy) < 100
+            want = orc.bucket_filter(200, 300, xy, np.zeros(len(xy), np.int32), resp.astype(np.int32))
+            fs = api.FeatureSet()
+            fs.appendFeaturesFromImage(im, 20)
+            assert fs.size() == len(want[1]), (rep, fs.size(), len(want[1]))
+            assert np.array_equal(bits(fs.points), bits(want[0])) and np.array_equal(fs.ages, want[1]) and np.array_equal(fs.strengths, want[2])
+            # and with existing tracks in the set (their order indices are what a stale key would be decoded against)
+            fs2 = api.FeatureSet(); fs2.points, fs2.ages, fs2.strengths = want[0][:3].copy(), want[1][:3].copy() + 2, want[2][:3].copy()
+            fs2.appendFeaturesFromImage(im, 20)
+            w2 = orc.bucket_filter(200, 300, np.concatenate([want[0][:3], xy]), np.concatenate([want[1][:3] + 2, np.zeros(len(xy), np.int32)]),
+                                   np.concatenate([want[2][:3], resp.astype(np.int32)]))
+            assert np.array_equal(bits(fs2.points), bits(w2[0])) and np.array_equal(fs2.ages, w2[1]) and np.array_equal(fs2.strengths, w2[2])
+
+
 # ---------------------------------------------------------------- pyramid
 @pytest.mark.parametrize("name,win,lv", [("texture", 10, 3), ("texture_odd", 10, 3), ("layers", 21, 3), ("layers", 21, 4), ("tiny", 7, 3)])
 def test_pyramid_bit_exact(api, name, win, lv):
