@@ -37,6 +37,56 @@ def host_cores():
     return max(1, min(n, 64))
 
 
+def opencv_probe(seq, cal, over, ping_pong, frames):
+    """BASELINE.md §3.2 / SURVEY §8d secondary CPU baseline: if THIS box has OpenCV 4 (never assumed, never installed), build
+    tools/opencv_baseline.cpp — own code calling the same seven cv:: functions with the reference's parameters — time it with
+    default threads and with one, and report it; otherwise say what was probed."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    probed, cflags, libs = [], None, None
+    if shutil.which("pkg-config"):
+        probed.append("pkg-config opencv4")
+        if subprocess.run(["pkg-config", "--exists", "opencv4"]).returncode == 0:
+            cflags = subprocess.check_output(["pkg-config", "--cflags", "opencv4"], text=True).split()
+            libs = subprocess.check_output(["pkg-config", "--libs", "opencv4"], text=True).split()
+    if cflags is None:
+        probed.append("ldconfig -p libopencv_video")
+        try:
+            have = "libopencv_video" in subprocess.run(["ldconfig", "-p"], capture_output=True, text=True).stdout
+        except Exception:
+            have = False
+        probed.append("/usr/include/opencv4, /usr/local/include/opencv4")
+        inc = [d for d in ("/usr/include/opencv4", "/usr/local/include/opencv4") if os.path.isdir(os.path.join(d, "opencv2"))]
+        if not have:
+            have = bool(glob.glob("/usr/lib/*/libopencv_video.so*") + glob.glob("/usr/local/lib/libopencv_video.so*"))
+        if have and inc:
+            cflags = ["-I" + inc[0]]
+            libs = ["-lopencv_calib3d", "-lopencv_video", "-lopencv_features2d", "-lopencv_imgproc", "-lopencv_core"]
+    if cflags is None:
+        return "not present (probed: %s)" % ", ".join(probed)
+    try:
+        tmp = tempfile.mkdtemp(prefix="svo_ocv_")
+        exe = os.path.join(tmp, "opencv_baseline")
+        subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++17", os.path.join(ROOT, "tools", "opencv_baseline.cpp"), "-o", exe] + cflags + libs,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        raw = os.path.join(tmp, "frames.raw")
+        order = [0] + [ping_pong(i) for i in range(1, frames + 1)]
+        with open(raw, "wb") as f:
+            for k in order:
+                f.write(np.ascontiguousarray(seq.left[k]).tobytes()); f.write(np.ascontiguousarray(seq.right[k]).tobytes())
+        out = {}
+        for label, threads in (("default_threads", 0), ("one_thread", 1)):
+            r = subprocess.run([exe, raw, str(cal["width"]), str(cal["height"]), str(len(order)), str(cal["fx"]), str(cal["cx"]), str(cal["cy"]), str(cal["bf"]),
+                                str(over["win_w"]), str(over["max_level"]), str(over["ransac_iterations"]), str(over["max_translation_norm"]), str(threads),
+                                os.path.join(tmp, "poses_%s.txt" % label)], capture_output=True, text=True, timeout=600)
+            out[label] = r.stdout.strip().split("\n")[-1] if r.returncode == 0 else "failed: " + r.stderr[-200:]
+        return {"present": True, "found_with": probed[-1], **out}
+    except Exception as e:                                     # an OpenCV that does not build / link is reported, not fatal
+        return "present but tools/opencv_baseline.cpp did not build or run: %r (probed: %s)" % (e, ", ".join(probed))
+
+
 def level_sizes(W, H, win, max_level):
     out = []
     w, h = W, H
@@ -73,6 +123,8 @@ def main():
                     "(RANSAC-PnP outliers; 0 = static scene, the best case for PnP).  Default: 0.3 for cfg2 (the metric's workload), 0 for the others")
     ap.add_argument("--frames", type=int, default=10, help="frames rendered per pool sequence (ping-pong replay)")
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--ate-frames", type=int, default=40, help="frame transitions of the ATE leg: one freshly rendered sequence (not a ping-pong "
+                    "replay) through a one-sequence context and through the CPU oracle, outside the timed region (0 = only the timed steps of slot 0)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg5"],
                     help="BASELINE.json configs[1] (the metric's configuration, default) / configs[2] / configs[4]; the others are extra measurements")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
@@ -180,7 +232,7 @@ def main():
     depth = max(1, min(args.depth, 8))
     poses = np.zeros((B, args.steps, 17))
     n_lk, n_ok, lk_ms, fr_ms = [], 0, [], []
-    n_bounds, n_inl, n_iters, n_vis, n_stp = [], [], [], [], []
+    n_bounds, n_inl, n_iters, n_vis, n_stp, n_dead = [], [], [], [], [], []
 
     def run(first, count, record):
         nonlocal n_ok
@@ -202,6 +254,7 @@ def main():
                     n_iters.append(np.mean([s.ransac_iters for s in vo.stats]))
                     n_vis.append(np.mean([s.lk_level_visits for s in vo.stats]))
                     n_stp.append(np.mean([s.lk_newton_steps for s in vo.stats]))
+                    n_dead.append(np.mean([[s.lk_dead_after_pass0, s.lk_dead_after_pass1, s.lk_dead_after_pass2] for s in vo.stats], axis=0))
                     n_ok += int(ok.sum())
                     poses[c * Bc:(c + 1) * Bc, col, :16] = T.reshape(Bc, 16); poses[c * Bc:(c + 1) * Bc, col, 16] = ok
             col += 1
@@ -231,14 +284,27 @@ def main():
         n_ok_all = int(okt.item())
     else:
         n_ok_all = n_ok
-
-    if rank == 0:
-        if grouped:                                           # rank 0 now holds every sequence's pose stream
+    # the dominant kernel's duration and every rank's own rate, so that an N > 1 line shows its slowest rank (a straggler GPU is
+    # what a scaling run is there to expose): max over ranks of the mean LK launch duration, and each rank's frame-pairs/s
+    lk_avg_ms = float(np.mean(lk_ms))
+    per_rank_value = [B * args.steps / dt_local]
+    lk_avg_ms_ranks = [lk_avg_ms]
+    if grouped:
+        mine = torch.tensor([B * args.steps / dt_local, lk_avg_ms], dtype=torch.float64, device=comm_dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank_value = [float(v[0].item()) for v in allv]
+        lk_avg_ms_ranks = [float(v[1].item()) for v in allv]
+        lk_avg_ms = max(lk_avg_ms_ranks)
+        if rank == 0:                                         # rank 0 now holds every sequence's pose stream
             assert len(gathered) == world and all(tuple(g.shape) == (B, args.steps, 17) for g in gathered)
             assert np.array_equal(gathered[0].cpu().numpy(), poses)
+        dist.barrier()
+        dist.destroy_process_group()                          # everything below is rank 0's own work (CPU baseline, ATE): no rank waits for it
+
+    if rank == 0:
         N = float(np.mean(n_lk))
         bytes_total, bytes_lk = algorithmic_bytes(W, H, N, win, over["max_level"], over["ransac_iterations"])
-        lk_avg_ms = float(np.mean(lk_ms))
         achieved = bytes_lk * Bc / (lk_avg_ms * 1e-3) / 1e9    # algorithmic GB/s of the dominant kernel: one launch covers Bc sequences
         value = world * B * args.steps / dt
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
@@ -275,7 +341,7 @@ def main():
                      "peak_TFLOPs": 157.3, "frac_at_job_rate": lk_flops * value / world / 157.3e12,
                      "frac_in_kernel": lk_flops * Bc / (lk_avg_ms * 1e-3) / 157.3e12}
         cpu = None
-        if world == 1 and args.cpu_frames > 0:
+        if args.cpu_frames > 0:                               # rank 0, any N: the timed region and the last barrier are behind us
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             # the CPU number is taken with -O3 -march=native, so that build is made HERE, on the machine that
             # times it (never shipped: a -march=native object from another host may not even run); same IEEE-strict flags
@@ -305,7 +371,7 @@ def main():
             single, _ = cpu_rate(1, max(4, args.cpu_frames // 3))
             allc, cores = cpu_rate(host_cores(), args.cpu_frames)   # every core this process is granted (OpenMP over LK points / image rows)
             orc.set_threads(1)
-            cpu = {"value": allc, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+            cpu = {"value": allc, "unit": "frame-pairs/s", "cores": cores, "kind": "port", "opencv": opencv_probe(pool[0], cal, over, ping_pong, args.cpu_frames),
                    "sample": "%d frame pairs of pool sequence 0 of the same workload through oracle/ — this repo's plain-C RESTATEMENT of the "
                              "reference's pipeline and of the OpenCV 4.5 calls it makes, NOT OpenCV itself (absent from the image) — built %s, "
                              "OpenMP over the points of each LK pass and over image rows, %d threads; single thread: %.2f frame-pairs/s"
@@ -323,6 +389,31 @@ def main():
             if common:
                 ate["vs_cpu_oracle_m"] = syn.ate_rmse(syn.integrate([est[c] for c in common]), syn.integrate([cpu_T[first + c] for c in common]))
                 ate["oracle_frames"] = len(common)
+        if args.ate_frames > 0:
+            # the metric's "ATE vs ref" on a real path: one freshly rendered sequence of ate_frames + 1 frames (forward motion, no
+            # ping-pong), through a one-sequence HIP context and, frame for frame, through the CPU oracle
+            sq = syn.StereoSequence(cal=cal, n_frames=args.ate_frames + 1, seed=seed0 + 7919, movers=args.movers, **scene)
+            g1 = api.BatchVisualOdometry(W, H, 1, api.default_config(**over), device=local_rank); g1.initalize_projection_matricies(Pl, Pr)
+            o1 = None
+            if cpu is not None:
+                orc.set_threads(host_cores())
+                o1 = orc.VisualOdometry(orc.default_config(**over)); o1.initalize_projection_matricies(Pl, Pr)
+            est_l, orc_l, n_same = [], [], 0
+            for k in range(args.ate_frames + 1):
+                okg, Tg = g1.stereo_callback_batch([sq.left[k]], [sq.right[k]])
+                if o1 is not None:
+                    oko, To = o1.stereo_callback(sq.left[k], sq.right[k])
+                    n_same += int(bool(okg[0]) == oko and {f[0]: getattr(o1.stats, f[0]) for f in o1.stats._fields_} == g1.stats[0].as_dict())
+                    if k: orc_l.append(To)
+                if k: est_l.append(Tg[0])
+            if o1 is not None:
+                orc.set_threads(1)
+            gt_l = [np.linalg.inv(sq.poses[k - 1]) @ sq.poses[k] for k in range(1, args.ate_frames + 1)]
+            ate["long_run"] = {"frames": args.ate_frames, "path_length_m": float(sum(np.linalg.norm(g[:3, 3]) for g in gt_l)),
+                               "vs_ground_truth_m": syn.ate_rmse(syn.integrate(est_l), syn.integrate(gt_l)),
+                               "vs_cpu_oracle_m": syn.ate_rmse(syn.integrate(est_l), syn.integrate(orc_l)) if orc_l else None,
+                               "frames_with_identical_flags_and_counters": n_same if o1 is not None else None}
+        dead = np.mean(n_dead, axis=0) if n_dead else np.zeros(3)
         out = {
             "metric": "stereo frame-pairs/sec on KITTI-00 1241x376 @2k feats; ATE vs ref", "value": value, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -333,6 +424,8 @@ def main():
                        "sequences_per_gpu": B, "contexts_per_gpu": C, "frames_in_flight": depth, "mean_features_into_lk": N,
                        "mean_tracks_after_bounds": float(np.mean(n_bounds)), "mean_inliers": float(np.mean(n_inl)),
                        "mean_ransac_iters": float(np.mean(n_iters)),
+                       "mean_features_dead_after_lk_pass_0_1_2": [float(v) for v in dead],
+                       "ate_frames": {"timed_steps_of_slot_0": args.steps, "long_run": args.ate_frames},
                        "distinct_streams": min(B, args.pool * max(1, (2 * F - 2) // 3)),
                        "distinct_rendered_sequences": args.pool, "frames_per_sequence": F,
                        "pose_ok_fraction": n_ok_all / float(world * B * args.steps)},
@@ -342,6 +435,7 @@ def main():
                          "kernel_avg_ms": lk_avg_ms, "frame_avg_ms": float(np.mean(fr_ms)),
                          "whole_frame_frac": bytes_total * value / world / 1e9 / PEAK_HBM_GBS},
             "cpu_baseline": cpu, "ate": ate,
+            "per_rank_value": per_rank_value, "per_rank_lk_kernel_avg_ms": lk_avg_ms_ranks,
             # the line's own proof that the device worked through the timed region (an smi sampler misses a region this short):
             # the LK launches' HIP-event durations of rank 0, summed, against rank 0's wall clock; launches of different contexts
             # run on different streams, so their tails may overlap and the share is an upper estimate of LK's part
@@ -349,8 +443,6 @@ def main():
                             "timed_region_ms": dt_local * 1e3, "lk_share_of_timed_region": float(np.sum(lk_ms)) / (dt_local * 1e3)},
         }
         print(json.dumps(out))
-    if grouped:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

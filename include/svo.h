@@ -58,6 +58,12 @@ typedef struct {
                                            * colour Mats): cv::FAST then walks the first `width` BYTES of every row (it has no channel
                                            * check), pyramids and LK are 3-channel.  Frame pipeline only (svo_process*, svo_submit_batch);
                                            * strides are in bytes.  Reproduces the trajectory the reference recorded for run1/. */
+    int lk_float_sums;                    /* 0 (default): the LK normal equations are summed as exact integers (order-independent, fastest).
+                                           * 1: they are summed in FLOAT in the lane order of OpenCV 4.x's SIMD128 code (lkpyramid.cpp,
+                                           * `#if CV_SIMD128 && !CV_NEON`), i.e. with OpenCV's own rounding.  Measured on the reference's
+                                           * recording: mode 1 reproduces run1/result.csv digit for digit (with channels = 3), mode 0 flips
+                                           * borderline tracks at 4 of its first 24 frames (1e-5 .. 1e-3 m).  Several times slower in
+                                           * LK (serial float chains); frame pipeline and svo_circular_matching only. */
 } svo_config;
 
 /* Per-frame counters — the numbers the reference prints at vo.cpp:226,239,326,331,365,108-110,128-130. */
@@ -71,8 +77,11 @@ typedef struct {
     int ransac_iters;       /* iterations the adaptive RANSAC loop would have run */
     int fail_reason;        /* 0 ok, 1 first frame, 2 too few tracks (vo.cpp:82), 3 RANSAC fail / few inliers (:106), 4 motion gate (:129) */
     int n_features_out;     /* size of currentVOFeatures on return */
-    int lk_level_visits;    /* (feature, pass, level) visits of the four LK passes that reached the Newton loop */
-    int lk_newton_steps;    /* Newton iterations of the four LK passes (the work term of the LK flop model) */
+    int lk_level_visits;    /* (feature, pass, level) visits of the LK passes that reached the Newton loop.  A feature runs its passes
+                             * up to and including the first one that returns status 0: vo.cpp:227-238 deletes it whatever the later
+                             * passes return, so the frame pipeline does not run them */
+    int lk_newton_steps;    /* Newton iterations of those passes (the work term of the LK flop model) */
+    int lk_dead_after_pass[3]; /* features whose status first became 0 in pass 0 (L0->L1), 1 (L1->R1), 2 (R1->R0) */
 } svo_frame_stats;
 
 typedef struct svo_context svo_context;
@@ -119,6 +128,14 @@ int svo_circular_matching(svo_context* ctx, const uint8_t* left_t1, const uint8_
 /* Asynchronous form for throughput: enqueue one frame for every sequence and return immediately
  * (device pointers only; the images must stay valid until the matching svo_collect).
  * Results are queued in order; svo_collect blocks for the oldest outstanding frame. At most 8 in flight. */
+/* Diagnostics: VGPRs one SIMD has left beside a full complement of this context's LK waves (-1 unknown).  Several many-sequence
+ * contexts on one device overlap their f64 kernels with each other's LK kernel only when this is >= 96 (w = 21: 100-register
+ * LK build, four waves, 96 left); tests pin it so that a change to the LK kernel that costs the overlap fails loudly.
+ * NOTE on locality: creating or destroying ANOTHER context with more than 8 sequences on the same device changes which builds of
+ * the PnP / triangulation kernels this context launches from its next frame on (full-register alone, 96-register when the
+ * device is shared) and whether its LK launches are chained behind the other's.  Results are identical either way. */
+int svo_get_lk_registers_left(svo_context* ctx);
+
 int svo_submit_batch(svo_context* ctx, const uint8_t* const* left_dev, const uint8_t* const* right_dev, int stride);
 int svo_collect(svo_context* ctx, double* T_out, int* ok_out, svo_frame_stats* stats);
 
@@ -148,10 +165,15 @@ void* svo_get_stream(svo_context* ctx);   /* hipStream_t the context launches on
  * Stage-level entry points (host arrays in / out, one call = upload + kernel(s) + download).
  * They run the same kernels as the frame pipeline and exist so the reference's own unit tests
  * (src/main.cpp:50-264) and the parity tests can exercise each stage alone.  Their device buffers are kept per calling thread
- * and reused while device, image size and configuration stay the same; svo_stage_cache_clear() releases them.
+ * and reused while device, image size and the buffer-shaping part of the configuration (bucket grid, LK window, levels, channels,
+ * at most the RANSAC iteration count they were allocated for) stay the same — other parameters are taken over in place.
+ * svo_stage_cache_clear() releases the calling thread's buffers.  A thread that exits hands its buffers to the next thread that
+ * needs some (they are not freed at thread exit, where the HIP runtime may be gone): svo_stage_cache_clear_all() frees every
+ * cached context that no live thread holds (plus the caller's) and returns how many it freed.
  * ---------------------------------------------------------------------------------------------- */
 
 void svo_stage_cache_clear(void);
+int svo_stage_cache_clear_all(void);
 
 /* replaces: featureDetectionFast(image, fast_threshold, response_strengths)  (vo.h:393-395, feature_set.cpp:55-68)
  * i.e. cv::FAST(.., nonmaxSuppression=true).  xy: cap x 2, resp: cap.  *n_out = total found (may exceed cap). */

@@ -88,6 +88,7 @@ typedef struct {
     int max_features;            /* build preset, NOT in the reference: 0 = unlimited; >0 keeps the
                                     first max_features of the bucketed set */
     int channels;                /* 1 = single-channel input (default), 3 = interleaved BGR as the reference CLI feeds (B-1) */
+    int lk_float_sums;           /* mirror of svo_config.lk_float_sums: 1 = this object's LK passes run with D1 reverted (ORC_OCV_D1_LK_FLOAT) */
 } orc_config;
 
 void orc_config_default(orc_config* c);
@@ -224,9 +225,12 @@ typedef struct {
     int ransac_iters;
     int fail_reason;        /* 0 ok, 1 first frame, 2 too few tracks, 3 ransac fail / few inliers, 4 motion gate */
     int n_features_out;     /* size of currentVOFeatures when the callback returns */
-    int lk_level_visits;    /* (point, pass, level) visits of the frame's four LK passes that reached the Newton loop */
-    int lk_newton_steps;    /* Newton iterations of the frame's four LK passes */
+    int lk_level_visits;    /* (point, pass, level) visits that reached the Newton loop, over the passes a feature runs: up to and including its first pass with status 0 */
+    int lk_newton_steps;    /* Newton iterations of those passes */
+    int lk_dead_after_pass[3]; /* features whose status first became 0 in pass k = 0 (L0->L1), 1 (L1->R1), 2 (R1->R0): vo.cpp:227-238 deletes them whatever the later passes return */
 } orc_frame_stats;
+typedef struct { long long level_visits, newton_steps; int dead_after_pass[3]; } orc_lk_chain_stats;
+extern orc_lk_chain_stats orc_last_chain_stats;   /* of the last orc_circular_match_cn call */
 extern long long orc_lk_counters[4];   /* running totals: [0] level visits that reached the Newton loop, [1] Newton iterations, [2] all visits */
 
 orc_vo* orc_vo_create(const orc_config* cfg);

@@ -124,6 +124,10 @@ void orc_pyramid_free(orc_pyramid* p) {
 
 /* debug counters (test infrastructure): [0] level visits that reached the Newton loop, [1] Newton iterations, [2] level visits total */
 long long orc_lk_counters[4] = {0, 0, 0, 0};
+/* optional per-point work arrays for the pass in progress (set by orc_circular_match_cn, NULL otherwise): += visits / steps of point i */
+static int* g_pt_visits = NULL;
+static int* g_pt_steps = NULL;
+orc_lk_chain_stats orc_last_chain_stats = {0, 0, {0, 0, 0}};
 
 #define W_BITS 14
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
@@ -270,6 +274,7 @@ static void lk_level(int cn, const orc_pyramid* const* Apl, const orc_pyramid* c
         }
         D = 1.f / D;
         cnt_visit++;
+        if (g_pt_visits) g_pt_visits[i]++;
         npx -= half_x; npy -= half_y;
         float pdx = 0.f, pdy = 0.f;
         for (j = 0; j < max_count; j++) {
@@ -279,6 +284,7 @@ static void lk_level(int cn, const orc_pyramid* const* Apl, const orc_pyramid* c
                 break;
             }
             cnt_step++;
+            if (g_pt_steps) g_pt_steps[i]++;
             a = npx - inx; b = npy - iny;
             iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
             iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
@@ -366,13 +372,29 @@ void orc_circular_match_cn(int cn, const orc_pyramid* const* l0, const orc_pyram
                         int n, const float* pl0, float* pl1, float* pr1, float* pr0, float* pl0_circle,
                         uint8_t* ok, const orc_config* cfg) {
     uint8_t* st = (uint8_t*)malloc((size_t)n * 4 + 4);
-    int i;
-    orc_lk_track_cn(cn, l0, l1, n, pl0, pl1, st, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold);          /* :203 */
-    orc_lk_track_cn(cn, l1, r1, n, pl1, pr1, st + n, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold);      /* :206 */
-    orc_lk_track_cn(cn, r1, r0, n, pr1, pr0, st + 2 * n, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold);  /* :209 */
-    orc_lk_track_cn(cn, r0, l0, n, pr0, pl0_circle, st + 3 * n, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold); /* :213 */
+    int* work = (int*)calloc((size_t)n * 8 + 8, sizeof(int));       /* [pass][visits | steps][point] */
+    int i, k;
+#define PASS(K, A, B, FROM, TO) g_pt_visits = work + (size_t)(2 * (K)) * n; g_pt_steps = work + (size_t)(2 * (K) + 1) * n; \
+    orc_lk_track_cn(cn, A, B, n, FROM, TO, st + (size_t)(K) * n, cfg->win_w, cfg->win_h, cfg->max_level, cfg->lk_max_count, cfg->lk_epsilon, cfg->optical_flow_min_eig_threshold)
+    PASS(0, l0, l1, pl0, pl1);          /* :203 */
+    PASS(1, l1, r1, pl1, pr1);          /* :206 */
+    PASS(2, r1, r0, pr1, pr0);          /* :209 */
+    PASS(3, r0, l0, pr0, pl0_circle);   /* :213 */
+#undef PASS
+    g_pt_visits = g_pt_steps = NULL;
     orc_find_close_points(n, pl0, pl0_circle, (float)cfg->circular_matching_success_threshold, ok);   /* :217-219 (float32 threshold parameter) */
     for (i = 0; i < n; i++) ok[i] = (uint8_t)(st[i] && st[n + i] && st[2 * n + i] && st[3 * n + i] && ok[i]);  /* :227-230 */
+    /* Work accounting of the frame pipeline (orc_frame_stats): a feature whose status is 0 after pass k is deleted at
+       vo.cpp:233-238 whatever the later passes return, so the HIP path does not run them; the counters count the passes up to and
+       including the first one that failed, and dead_after_pass[k] the features that first failed in pass k = 0, 1, 2. */
+    memset(&orc_last_chain_stats, 0, sizeof(orc_last_chain_stats));
+    for (i = 0; i < n; i++)
+        for (k = 0; k < 4; k++) {
+            orc_last_chain_stats.level_visits += work[(size_t)(2 * k) * n + i];
+            orc_last_chain_stats.newton_steps += work[(size_t)(2 * k + 1) * n + i];
+            if (!st[(size_t)k * n + i]) { if (k < 3) orc_last_chain_stats.dead_after_pass[k]++; break; }
+        }
+    free(work);
     free(st);
 }
 

@@ -29,7 +29,7 @@ void orc_config_default(orc_config* c) {
     c->ransac_iterations = 100; c->optical_flow_min_eig_threshold = 0.001;
     c->circular_matching_success_threshold = .15; c->max_translation_norm = .1; c->max_rotation_norm = .5;
     c->win_w = 10; c->win_h = 10; c->max_level = 3; c->lk_max_count = 30; c->lk_epsilon = 0.0001;
-    c->ransac_confidence = 0.98f; c->max_features = 0; c->channels = 1;
+    c->ransac_confidence = 0.98f; c->max_features = 0; c->channels = 1; c->lk_float_sums = 0;
 }
 
 struct orc_vo {
@@ -195,8 +195,15 @@ int orc_vo_stereo_callback_cn(orc_vo* vo, const uint8_t* left, const uint8_t* ri
         for (k = 0; k < cn; k++) { l0[k] = &vo->pyrL0[k]; r0[k] = &vo->pyrR0[k]; l1[k] = &pl1p[k]; r1[k] = &pr1p[k]; }
         {
             const long long v0 = orc_lk_counters[0], s0 = orc_lk_counters[1];       /* (one VisualOdometry at a time per process: test infrastructure) */
-            orc_circular_match_cn(cn, l0, r0, l1, r1, n, pl0, pl1, pr1, pr0, plc, ok, c);   /* :203-230 */
-            st->lk_level_visits = (int)(orc_lk_counters[0] - v0); st->lk_newton_steps = (int)(orc_lk_counters[1] - s0);
+            {   /* cfg.lk_float_sums mirrors svo_config.lk_float_sums: deviation D1 reverted for this object's LK passes */
+                const unsigned prev_mode = orc_get_opencv_mode();
+                if (c->lk_float_sums) orc_set_opencv_mode(prev_mode | ORC_OCV_D1_LK_FLOAT);
+                orc_circular_match_cn(cn, l0, r0, l1, r1, n, pl0, pl1, pr1, pr0, plc, ok, c);   /* :203-230 */
+                orc_set_opencv_mode(prev_mode);
+            }
+            (void)v0; (void)s0;
+            st->lk_level_visits = (int)orc_last_chain_stats.level_visits; st->lk_newton_steps = (int)orc_last_chain_stats.newton_steps;
+            for (k = 0; k < 3; k++) st->lk_dead_after_pass[k] = orc_last_chain_stats.dead_after_pass[k];
         }
         for (k = 0; k < cn; k++) {
             orc_pyramid_free(&vo->pyrL0[k]); orc_pyramid_free(&vo->pyrR0[k]);

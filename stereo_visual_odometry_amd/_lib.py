@@ -46,13 +46,15 @@ class SvoConfig(C.Structure):
         ("max_translation_norm", C.c_double), ("max_rotation_norm", C.c_double),
         ("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int), ("lk_max_count", C.c_int),
         ("lk_epsilon", C.c_double), ("ransac_confidence", C.c_float), ("max_features", C.c_int), ("channels", C.c_int),
+        ("lk_float_sums", C.c_int),
     ]
 
 
 class SvoFrameStats(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "n_after_detect", "second_pass", "n_into_lk", "n_after_circular", "n_after_bounds",
-        "n_inliers", "ransac_iters", "fail_reason", "n_features_out", "lk_level_visits", "lk_newton_steps")]
+        "n_inliers", "ransac_iters", "fail_reason", "n_features_out", "lk_level_visits", "lk_newton_steps",
+        "lk_dead_after_pass0", "lk_dead_after_pass1", "lk_dead_after_pass2")]
 
     def as_dict(self):
         return {f[0]: getattr(self, f[0]) for f in self._fields_}
@@ -68,9 +70,9 @@ lib.svo_get_stream.argtypes = [C.c_void_p]
 EXPORTS = [
     "svo_last_error", "svo_device_count", "svo_config_default", "svo_create", "svo_destroy", "svo_set_projection",
     "svo_process_batch", "svo_process", "svo_circular_matching", "svo_submit_batch", "svo_collect", "svo_get_features", "svo_get_last_tracks",
-    "svo_get_last_timing", "svo_set_stage_timing", "svo_get_stage_timing", "svo_get_stream", "svo_fast_detect", "svo_fast_score_map", "svo_bucket_filter",
+    "svo_get_lk_registers_left", "svo_get_last_timing", "svo_set_stage_timing", "svo_get_stage_timing", "svo_get_stream", "svo_fast_detect", "svo_fast_score_map", "svo_bucket_filter",
     "svo_append_features_from_image", "svo_build_pyramid", "svo_lk_track", "svo_circular_match",
-    "svo_find_close_points", "svo_stage_cache_clear", "svo_triangulate", "svo_camera_to_world", "svo_inverse_transform",
+    "svo_find_close_points", "svo_stage_cache_clear", "svo_stage_cache_clear_all", "svo_triangulate", "svo_camera_to_world", "svo_inverse_transform",
 ]
 
 

@@ -9,6 +9,7 @@
 #include <stddef.h>
 #include <stdlib.h>
 #include <string>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include <math.h>
@@ -32,7 +33,7 @@ static int fail_arg(const char* msg) { g_err = msg; return SVO_ERR_ARG; }
 // The LK kernel of a many-sequence context fills the whole GPU.  When several such contexts share a device (bench.py interleaves
 // two, so that one's latency-bound PnP kernels run under the other's LK), their LK launches are chained through one event per
 // device: two LK grids resident together only halve each other's CUs, and HIP-event durations of either would include the other.
-struct LkGate { std::mutex mu; hipEvent_t ev = nullptr; bool armed = false; int contexts = 0; };
+struct LkGate { std::mutex mu; hipEvent_t ev = nullptr; bool armed = false; std::atomic<int> contexts{0}; };
 static LkGate g_lk_gate[SVO_MAX_DEVICES];
 static bool lk_gated(const svo_context* c);
 
@@ -49,7 +50,7 @@ extern "C" void svo_config_default(svo_config* c) {
     c->ransac_iterations = 100; c->optical_flow_min_eig_threshold = 0.001;
     c->circular_matching_success_threshold = .15; c->max_translation_norm = .1; c->max_rotation_norm = .5;
     c->win_w = 10; c->win_h = 10; c->max_level = 3; c->lk_max_count = 30; c->lk_epsilon = 0.0001;
-    c->ransac_confidence = 0.98f; c->max_features = 0; c->channels = 1;
+    c->ransac_confidence = 0.98f; c->max_features = 0; c->channels = 1; c->lk_float_sums = 0;
 }
 
 // cv::buildOpticalFlowPyramid's level rule: level 0 always, stop as soon as
@@ -93,9 +94,10 @@ struct svo_context {
     bool capturing = false;                      // inside hipStreamBeginCapture / EndCapture
     bool counted = false;                        // this context is in its device's LkGate count
     int lk_room = -1;                            // lk_registers_left(d), asked once
+    int k_alloc = 0;                             // RANSAC hypotheses the PnP buffers were allocated for
     bool stage_timing = false;                   // record the four stage-boundary events of a frame (svo_set_stage_timing; SVO_STAGE_TIMING=1)
     hipGraphExec_t gexec[SVO_RING] = {};
-    int g_stride[SVO_RING] = {}, g_gn[SVO_RING] = {};
+    int g_stride[SVO_RING] = {}, g_gn[SVO_RING] = {}, g_co[SVO_RING] = {};   // what the slot's graph was captured with (stride, LK grid, co-resident builds)
     bool staged_slot[SVO_RING] = {};             // the slot's stage events were recorded (launch-list mode only)
 };
 
@@ -121,6 +123,7 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     if (cfg.buckets_along_height < 1 || cfg.buckets_along_width < 1 || cfg.ransac_iterations < 1) return fail_arg("bad bucket grid / ransac_iterations");
     if (cfg.channels == 0) cfg.channels = 1;
     if (cfg.channels != 1 && cfg.channels != 3) return fail_arg("channels must be 1 or 3");
+    if (cfg.lk_float_sums != 0 && cfg.lk_float_sums != 1) return fail_arg("lk_float_sums must be 0 or 1");
     if (!lk_window_supported_cn(cfg.win_w, cfg.channels)) return fail_arg("this LK window is not built for 3-channel input (5 .. 21 are)");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -131,7 +134,7 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     DevBuffers& d = c->d;
-    d.B = n_seq; d.cfg = cfg; d.K = cfg.ransac_iterations; d.CN = cfg.channels;
+    d.B = n_seq; d.cfg = cfg; d.K = cfg.ransac_iterations; d.CN = cfg.channels; c->k_alloc = d.K;
     d.NB = cfg.buckets_along_height * cfg.buckets_along_width;
     d.bucket_h = (height + cfg.buckets_along_height - 1) / cfg.buckets_along_height;     // feature_set.cpp:91-93,103-104
     d.bucket_w = (width + cfg.buckets_along_width - 1) / cfg.buckets_along_width;
@@ -226,9 +229,11 @@ extern "C" int svo_create(const svo_config* cfg, int device, int n_seq, int widt
 
 // Chaining the LK launches and running the f64 kernels as 96-register builds pays only if those builds fit beside a resident LK
 // grid (lk_registers_left: w = 21 yes, w = 10 no — there the contexts' LK grids are left to overlap each other, measured +3 %).
+// `contexts` is an atomic: contexts are created and destroyed on other threads while this one enqueues frames; a frame reads it
+// ONCE (issue_frame) and uses that one answer for both decisions it drives (the 96-register builds and the chained LK launches).
 static bool lk_gated(const svo_context* c) {
     static const bool off = getenv("SVO_LK_GATE") && atoi(getenv("SVO_LK_GATE")) == 0;
-    return !off && c->counted && c->lk_room >= 96 && g_lk_gate[c->device].contexts > 1;
+    return !off && c->counted && c->lk_room >= 96 && g_lk_gate[c->device].contexts.load(std::memory_order_relaxed) > 1;
 }
 
 extern "C" void svo_destroy(svo_context* c) {
@@ -262,6 +267,8 @@ extern "C" void svo_destroy(svo_context* c) {
 
 extern "C" void* svo_get_stream(svo_context* c) { return c ? (void*)c->stream : nullptr; }
 
+extern "C" int svo_get_lk_registers_left(svo_context* c) { return c ? c->lk_room : -1; }
+
 extern "C" int svo_set_projection(svo_context* c, int seq, const float Pl[12], const float Pr[12]) {
     if (!c || !Pl || !Pr) return fail_arg("null argument");
     if (seq < -1 || seq >= c->d.B) return fail_arg("seq out of range");
@@ -289,25 +296,26 @@ static int stage_host_images(svo_context* c, const uint8_t* const* left, const u
 
 // The launch list of one frame (vo.cpp:41-137 as kernels), between the pointer-table upload and the result download.
 // with_events: record the stage-boundary events (not inside a graph capture).
-static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_events) {
+static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_events, int shares = -1) {
     DevBuffers& d = c->d;
     const int B = d.B;
     hipStream_t s = c->stream;
     static const bool force_lean = getenv("SVO_FORCE_LEAN") && atoi(getenv("SVO_FORCE_LEAN")) != 0;      // test knob: every context takes them
-    d.co_resident = (lk_gated(c) || force_lean) ? 1 : 0;               // picks the 96-register builds of the f64 kernels (svo_kernels_pnp.hip)
+    const bool shares_device = shares < 0 ? lk_gated(c) : shares != 0;   // read once per frame: both uses below see the same answer
+    d.co_resident = (shares_device || force_lean) ? 1 : 0;             // picks the 96-register builds of the f64 kernels (svo_kernels_pnp.hip)
     const uint8_t** dp = d.img_ptrs + (size_t)slot * 2 * B;         // the slot's pointer table: pinned host memory the kernel reads in place
     launch_ingest_pyramid(d, dp, stride, s, true);                    // + the per-frame reset
     if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
     launch_detect(d, 0, -1, s);
     launch_detect(d, 1, -1, s);
-    const bool gated = !c->capturing && lk_gated(c);
+    const bool gated = !c->capturing && shares_device;
     if (gated) {
         LkGate& g = g_lk_gate[c->device];
         std::lock_guard<std::mutex> lock(g.mu);
         if (g.armed) HIPCHK(hipStreamWaitEvent(s, g.ev, 0));
     }
     if (with_events) HIPCHK(hipEventRecord(c->ev_lk0[slot], s));
-    launch_lk_chain(d, gn, s);
+    if (!launch_lk_chain(d, gn, s, 1)) { g_err = "no LK kernel is built for this window / lanes-per-feature / channel count"; return SVO_ERR_STATE; }
     if (with_events) HIPCHK(hipEventRecord(c->ev_lk1[slot], s));
     if (gated) {
         LkGate& g = g_lk_gate[c->device];
@@ -342,13 +350,19 @@ static int enqueue_frame(svo_context* c, const uint8_t* const* left_dev, const u
     HIPCHK(hipEventRecord(c->ev_f0[slot], s));
     bool replayed = false;
     if (c->use_graph) {
-        if (!c->gexec[slot] || c->g_stride[slot] != stride || c->g_gn[slot] != gn) {
+        // the captured launch list bakes in which builds of the f64 kernels run: a context captured while it had the device to
+        // itself must be re-captured once another many-sequence context exists (and back), or it would keep the full-register
+        // builds that cannot start beside the other's LK grid
+        static const bool force_lean_g = getenv("SVO_FORCE_LEAN") && atoi(getenv("SVO_FORCE_LEAN")) != 0;
+        const int shares_now = lk_gated(c) ? 1 : 0;
+        const int co_now = (shares_now || force_lean_g) ? 1 : 0;
+        if (!c->gexec[slot] || c->g_stride[slot] != stride || c->g_gn[slot] != gn || c->g_co[slot] != co_now) {
             if (c->gexec[slot]) { (void)hipGraphExecDestroy(c->gexec[slot]); c->gexec[slot] = nullptr; }
             hipGraph_t g = nullptr;
             bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 c->capturing = true;
-                const int rc = issue_frame(c, slot, stride, gn, false);
+                const int rc = issue_frame(c, slot, stride, gn, false, shares_now);
                 c->capturing = false;
                 ok = (hipStreamEndCapture(s, &g) == hipSuccess) && rc == SVO_OK && g;
             }
@@ -357,7 +371,7 @@ static int enqueue_frame(svo_context* c, const uint8_t* const* left_dev, const u
             if (!ok) {                                                // capture is an optimisation: without it the same launches are issued directly
                 (void)hipGetLastError();
                 c->gexec[slot] = nullptr; c->use_graph = false;
-            } else { c->g_stride[slot] = stride; c->g_gn[slot] = gn; }
+            } else { c->g_stride[slot] = stride; c->g_gn[slot] = gn; c->g_co[slot] = co_now; }
         }
         if (c->use_graph) { HIPCHK(hipGraphLaunch(c->gexec[slot], s)); replayed = true; }
     }
@@ -480,6 +494,12 @@ extern "C" int svo_circular_matching(svo_context* c, const uint8_t* left_t1, con
     SeqState hs; int rc = read_state(c, 0, &hs); if (rc != SVO_OK) return rc;
     if (hs.frame_id < 1 || hs.slot_pyr_t0 < 0) { g_err = "no cached pyramids: call svo_process first (the reference primes them in stereo_callback, vo.cpp:47-56)"; return SVO_ERR_STATE; }
     const SeqState keep = hs;
+    // every error return below leaves the context's tracking state as it was: the guard writes `keep` back unless the call
+    // completes (then the state with the new cached pyramids is written instead)
+    struct Restore {
+        svo_context* c; const SeqState* st; bool armed = true;
+        ~Restore() { if (armed) { (void)hipMemcpyAsync(c->d.st, st, sizeof(SeqState), hipMemcpyHostToDevice, c->stream); (void)hipStreamSynchronize(c->stream); } }
+    } restore{c, &keep};
     int t1 = 0;
     for (int k = 0; k < 3; k++) if (k != hs.slot_img_t0 && k != hs.slot_pyr_t0) { t1 = k; break; }
     // the points go into the idle half of the feature double-buffer (scratch between frames); the state is put back below
@@ -491,7 +511,7 @@ extern "C" int svo_circular_matching(svo_context* c, const uint8_t* left_t1, con
     if ((rc = stage_host_images(c, l, r, stride, lp, rp)) != SVO_OK) return rc;
     const uint8_t** hp = c->h_ptrs; hp[0] = lp[0]; hp[1] = rp[0];
     launch_ingest_pyramid(c->d, c->d.img_ptrs, c->d.geom.W * c->d.CN, c->stream, false);          // vo.cpp:200-201
-    launch_lk_chain(c->d, n, c->stream);                                          // vo.cpp:203-230
+    if (!launch_lk_chain(c->d, n, c->stream, 0)) { g_err = "no LK kernel is built for this window / lanes-per-feature / channel count"; return SVO_ERR_STATE; }   // vo.cpp:203-230 (the caller gets every pass's raw points)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(pl1, c->d.pl1, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(pr1, c->d.pr1, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
@@ -502,7 +522,9 @@ extern "C" int svo_circular_matching(svo_context* c, const uint8_t* left_t1, con
     for (int i = 0; i < n; i++) ok[i] &= 1;                                       // bit0 = status0..3 && loop closure (vo.cpp:227-230)
     SeqState out = keep;
     out.slot_pyr_t0 = t1;                                                         // lastLeftPyramid = pyramidl1 (vo.cpp:231-232)
-    return set_state(c, out);
+    rc = set_state(c, out);
+    if (rc == SVO_OK) restore.armed = false;
+    return rc;
 }
 
 extern "C" int svo_set_stage_timing(svo_context* c, int on) {
@@ -608,19 +630,67 @@ static bool cfg_equal(const svo_config& a, const svo_config& b) {
            a.circular_matching_success_threshold == b.circular_matching_success_threshold && a.max_translation_norm == b.max_translation_norm &&
            a.max_rotation_norm == b.max_rotation_norm && a.win_w == b.win_w && a.win_h == b.win_h && a.max_level == b.max_level &&
            a.lk_max_count == b.lk_max_count && a.lk_epsilon == b.lk_epsilon && a.ransac_confidence == b.ransac_confidence &&
-           a.max_features == b.max_features && a.channels == b.channels;
+           a.max_features == b.max_features && a.channels == b.channels && a.lk_float_sums == b.lk_float_sums;
+}
+// the fields of a configuration that size or shape a context's device buffers (everything else is a parameter kernels read)
+static bool cfg_same_shape(const svo_config& a, const svo_config& b) {
+    return a.bucket_start_row == b.bucket_start_row && a.buckets_along_height == b.buckets_along_height && a.buckets_along_width == b.buckets_along_width &&
+           a.features_per_bucket == b.features_per_bucket && a.win_w == b.win_w && a.win_h == b.win_h && a.max_level == b.max_level && a.channels == b.channels;
+}
+// A cached stage context takes a new configuration IN PLACE when only parameters changed (thresholds, iteration counts up to the
+// allocated number, confidence, termination criteria, ...): callers that alternate such parameters between calls keep their
+// buffers instead of paying a context's worth of hipMalloc / hipFree per call.
+static bool stage_reconfigure(svo_context* c, const svo_config& cfg) {
+    if (!cfg_same_shape(c->d.cfg, cfg) || cfg.ransac_iterations < 1 || cfg.ransac_iterations > c->k_alloc) return false;
+    DevBuffers& d = c->d;
+    d.cfg = cfg; d.K = cfg.ransac_iterations;
+    c->lk_grid = (cfg.max_features > 0 && cfg.max_features < d.CAP) ? cfg.max_features : d.CAP;
+    d.lk_mineig_cut = lk_mineig_cut(cfg.win_w, cfg.optical_flow_min_eig_threshold);
+    double pc = (double)cfg.ransac_confidence; pc = pc > 0. ? pc : 0.; pc = pc < 1. ? pc : 1.;
+    d.ransac_log_num = log(1. - pc > 2.2250738585072014e-308 ? 1. - pc : 2.2250738585072014e-308);
+    c->lk_room = lk_registers_left(d);
+    return true;
 }
 struct StageCache { svo_context* c = nullptr; svo_config cfg; int device = -1, w = 0, h = 0; };
-static thread_local StageCache g_stage;
+// One cached context per calling thread.  The thread_local slot holds the pointer for speed; a mutex-protected registry owns the
+// contexts, so that (a) a thread that exits hands its context back (its slot's destructor marks the entry free — the context is
+// then REUSED by the next thread that needs one of the same shape, or freed by svo_stage_cache_clear_all), and (b) nothing is
+// destroyed from a thread-exit destructor, where the HIP runtime may already be gone.  Short-lived worker threads therefore
+// cost at most one context per concurrently LIVE thread, not one per thread ever started.
+struct StageEntry { StageCache sc; bool in_use = false; };
+static std::mutex g_stage_mu;
+static std::vector<StageEntry*> g_stage_all;
+struct StageSlot {
+    StageEntry* e = nullptr;
+    ~StageSlot() { if (e) { std::lock_guard<std::mutex> lock(g_stage_mu); e->in_use = false; e = nullptr; } }
+};
+static thread_local StageSlot g_stage_slot;
+static StageCache& stage_cache_of_this_thread(const svo_config& cfg, int device, int w, int h, int cap) {
+    if (!g_stage_slot.e) {
+        std::lock_guard<std::mutex> lock(g_stage_mu);
+        StageEntry* pick = nullptr;
+        for (StageEntry* e : g_stage_all)                              // an orphan of the same shape first, then any orphan
+            if (!e->in_use && e->sc.c && e->sc.device == device && e->sc.w == w && e->sc.h == h && e->sc.c->d.CAP >= cap) { pick = e; break; }
+        if (!pick) for (StageEntry* e : g_stage_all) if (!e->in_use) { pick = e; break; }
+        if (!pick) { pick = new StageEntry(); g_stage_all.push_back(pick); }
+        pick->in_use = true;
+        g_stage_slot.e = pick;
+    }
+    (void)cfg;
+    return g_stage_slot.e->sc;
+}
 static int stage_ctx(const svo_config& cfg_in, int device, int w, int h, int cap, svo_context** out) {
     svo_config cfg = cfg_in;
     if (cfg.channels == 0) cfg.channels = 1;
-    StageCache& sc = g_stage;
-    if (sc.c && sc.device == device && sc.w == w && sc.h == h && cfg_equal(sc.cfg, cfg) && sc.c->d.CAP >= cap) {
+    StageCache& sc = stage_cache_of_this_thread(cfg, device, w, h, cap);
+    if (sc.c && sc.device == device && sc.w == w && sc.h == h && sc.c->d.CAP >= cap) {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamSynchronize(sc.c->stream));
-        *out = sc.c;
-        return SVO_OK;
+        if (cfg_equal(sc.cfg, cfg) || stage_reconfigure(sc.c, cfg)) {
+            sc.cfg = cfg;
+            *out = sc.c;
+            return SVO_OK;
+        }
     }
     if (sc.c) { svo_destroy(sc.c); sc.c = nullptr; }
     int rc = ctx_create(&cfg, device, 1, w, h, cap, &sc.c);
@@ -629,8 +699,15 @@ static int stage_ctx(const svo_config& cfg_in, int device, int w, int h, int cap
     *out = sc.c;
     return SVO_OK;
 }
-extern "C" void svo_stage_cache_clear(void) {
-    if (g_stage.c) { svo_destroy(g_stage.c); g_stage.c = nullptr; }
+extern "C" void svo_stage_cache_clear(void) {                       // this thread's cached context
+    if (g_stage_slot.e && g_stage_slot.e->sc.c) { svo_destroy(g_stage_slot.e->sc.c); g_stage_slot.e->sc.c = nullptr; }
+}
+extern "C" int svo_stage_cache_clear_all(void) {                    // every cached context no live call is using (exited threads' too); returns how many were freed
+    std::lock_guard<std::mutex> lock(g_stage_mu);
+    int freed = 0;
+    for (StageEntry* e : g_stage_all)
+        if (e->sc.c && (!e->in_use || e == g_stage_slot.e)) { svo_destroy(e->sc.c); e->sc.c = nullptr; freed++; }
+    return freed;
 }
 
 // Level 0 of (slot, cam) <- a host image.  Rows are packed into pinned memory first: a 2-D copy from pageable memory degenerates
@@ -820,7 +897,7 @@ extern "C" int svo_circular_match(int device, const svo_config* cfg_in, const ui
     hs.frame_id = 1; hs.active = 1; hs.slot_img_t0 = 0; hs.slot_pyr_t0 = 0; hs.n_feat = n; hs.feat_buf = 0;
     if ((rc = build_pyramid_in_slot(c, hs, 1)) != SVO_OK) return rc;             // leaves slot_t1 = 1
     HIPCHK(hipMemcpyAsync(c->d.feat_xy[0], pl0, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
-    launch_lk_chain(c->d, n, c->stream);
+    if (!launch_lk_chain(c->d, n, c->stream, 0)) { g_err = "no LK kernel is built for this window / lanes-per-feature / channel count"; return SVO_ERR_STATE; }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(pl1, c->d.pl1, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(pr1, c->d.pr1, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));

@@ -71,7 +71,7 @@ struct DevBuffers {
     int* slot_n;                               // [B][NB]
     float2 *pl0, *pl1, *pr1, *pr0, *plc;       // [B][CAP] raw LK outputs
     uint8_t* okmask;                           // [B][CAP] bit0 circular ok, bit1 in-bounds
-    unsigned* lk_work;                         // [B][CAP] per feature: Newton steps << 8 | level visits of its four passes (summed by k_compact)
+    unsigned* lk_work;                         // [B][CAP] per feature: Newton steps << 8 | (1 + first pass with status 0, or 0) << 6 | level visits (summed by k_compact)
     float2 *tl0, *tr0, *tl1, *tr1;             // [B][CAP] compacted tracks
     float* world;                              // [B][CAP][3]
     uint8_t* inlier;                           // [B][CAP]
@@ -106,7 +106,8 @@ void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptr
 void launch_pyramid(const DevBuffers& d, hipStream_t s);
 void launch_ingest_pyramid(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride_bytes, hipStream_t s, bool begin_frame);   // both, fewer launches
 void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s);   // pass 0: FAST_THRESHOLD, pass 1: /4 if needed; th_override >= 0 replaces it
-void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t s);      // grid_n = max features that can enter LK
+// grid_n = max features that can enter LK; early_out: a feature stops at its first pass with status 0 (frame pipeline) or runs all four (member call)
+bool launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t s, int early_out);   // false: no kernel built for this (window, lanes, channels) — nothing ran
 void launch_compact(const DevBuffers& d, hipStream_t s);
 void launch_triangulate(const DevBuffers& d, hipStream_t s);
 void launch_pnp(const DevBuffers& d, hipStream_t s);                   // expects the subsets drawn (launch_triangulate does it)

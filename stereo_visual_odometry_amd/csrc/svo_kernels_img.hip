@@ -837,12 +837,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_compact(DevBuffers d) {
     float2* nxy = d.feat_xy[fb ^ 1] + o; int* nage = d.feat_age[fb ^ 1] + o; int* nstr = d.feat_str[fb ^ 1] + o;
     int run = 0, cntc = 0;
     unsigned visits = 0, steps = 0;                                  // svo_frame_stats.lk_level_visits / lk_newton_steps
+    unsigned dead0 = 0, dead1 = 0, dead2 = 0;                        // svo_frame_stats.lk_dead_after_pass: features that first failed in pass 0, 1, 2
     for (int base = 0; base < n; base += SCAN_THREADS) {
         const int i = base + threadIdx.x;
         uint8_t m = 0;
         if (i < n) {
             m = d.okmask[o + i];
-            const unsigned wk = d.lk_work[o + i]; visits += wk & 0xFFu; steps += wk >> 8;
+            const unsigned wk = d.lk_work[o + i]; visits += wk & 0x3Fu; steps += wk >> 8;
+            const unsigned dk = (wk >> 6) & 3u; dead0 += dk == 1u; dead1 += dk == 2u; dead2 += dk == 3u;
         }
         const bool keep = m == 3;
         cntc += m & 1;
@@ -858,8 +860,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_compact(DevBuffers d) {
             nxy[pos] = fxy[i]; nage[pos] = fage[i] + 1; nstr[pos] = fstr[i];
         }
     }
-    for (int k = 32; k > 0; k >>= 1) { visits += __shfl_xor(visits, k); steps += __shfl_xor(steps, k); cntc += __shfl_xor(cntc, k); }
+    for (int k = 32; k > 0; k >>= 1) { visits += __shfl_xor(visits, k); steps += __shfl_xor(steps, k); cntc += __shfl_xor(cntc, k);
+                                     dead0 += __shfl_xor(dead0, k); dead1 += __shfl_xor(dead1, k); dead2 += __shfl_xor(dead2, k); }
     if (lane == 0 && (visits | steps)) { atomicAdd(&s.stats.lk_level_visits, (int)visits); atomicAdd(&s.stats.lk_newton_steps, (int)steps); }
+    if (lane == 0 && (dead0 | dead1 | dead2)) {
+        atomicAdd(&s.stats.lk_dead_after_pass[0], (int)dead0); atomicAdd(&s.stats.lk_dead_after_pass[1], (int)dead1); atomicAdd(&s.stats.lk_dead_after_pass[2], (int)dead2);
+    }
     if (lane == 0) sh_c[wv] = cntc;
     __syncthreads();
     if (threadIdx.x == 0) {

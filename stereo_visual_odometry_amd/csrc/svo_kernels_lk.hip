@@ -261,6 +261,83 @@ __device__ __forceinline__ void load_pairs(const uint8_t* __restrict__ p, unsign
     }
 }
 
+
+// ---- "float sums" mode (svo_config.lk_float_sums; deviation D1 of the oracle reverted) -----------------------------------------
+// OpenCV accumulates the LK normal equations in FLOAT, in the lane order of its SIMD128 code (lkpyramid.cpp, `#if CV_SIMD128 &&
+// !CV_NEON`, acctype = float).  Float addition is not associative, so reproducing its bits means reproducing its ORDER: a window
+// row is E = W * CN interleaved elements (element e = pixel e / CN, channel e % CN); the vector loop takes 8 elements per step
+// (NSIMD = 8 * (E / 8) of them), the scalar tail the rest.
+//   A:  element e < NSIMD goes to float lane e & 3 of qA11 / qA12 / qA22 (q = fx * fy + q, unfused), rows in order; tail elements
+//       go, in order, to the scalar iA; at the end iA += (q0 + q2) + (q1 + q3).
+//   b:  v_dotprod pairs element 8g + k with 8g + k + 4 (k = 0..3) as an exact int32, v_cvt_f32, and adds it to one of eight float
+//       lanes (k, x|y); the tail adds (float)(diff * I) to ib; at the end ib1 += (k0x + k2x) + (k1x + k3x).
+// Measured against the reference's own recording (tools/deviation_ablation.py): this order reproduces run1/result.csv digit for
+// digit, the exact-integer sums of the default mode flip borderline tracks at frames 14, 15, 22, 23.
+// Mapping: the owner lanes write their per-element integers to LDS ([row][e]); five CHAIN lanes per sum (four SIMD lanes + the
+// tail) walk their elements in OpenCV's order with one dependent float add each — a serial chain by construction (105 adds for
+// the tail at W = 21), which is why this mode costs several times the default's Newton step and is opt-in.
+template <int W, int CN> struct LkFs {
+    static constexpr int E = W * CN, NSIMD = (E / 8) * 8;
+    static constexpr int CNT_S = NSIMD / 4, CNT_T = E - NSIMD, MAXC = CNT_S > CNT_T ? CNT_S : CNT_T;     // A: elements per row of a SIMD / the tail chain
+    static constexpr int NG = NSIMD / 8, MAXB = NG > CNT_T ? NG : CNT_T;                               // b: items per row
+    static constexpr int LDS_INTS = 2 * W * E;
+};
+__device__ __forceinline__ float lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// lds[row * E + e] = (ix & 0xFFFF) | (iy << 16).  Chain lanes: lane = which * 8 + c, which = 0 (A11), 1 (A12), 2 (A22), c = 0..3
+// the SIMD float lanes, c = 4 the scalar tail.  Returns the three sums (identical in every lane).
+template <int W, int CN>
+__device__ __forceinline__ void fs_sum_A(const int* __restrict__ lds, float (&As)[3]) {
+    using F = LkFs<W, CN>;
+    const int lane = threadIdx.x & 63, c = lane & 7, which = lane >> 3;
+    const int e0 = c < 4 ? c : F::NSIMD, stride = c < 4 ? 4 : 1;
+    const int cnt = (which < 3) ? (c < 4 ? F::CNT_S : (c == 4 ? F::CNT_T : 0)) : 0;
+    float acc = 0.f;
+    for (int y = 0; y < W; y++) {
+        const int* rp = lds + y * F::E + e0;
+#pragma unroll
+        for (int i = 0; i < F::MAXC; i++) {
+            if (i < cnt) {
+                const int v = rp[i * stride];
+                const float fx = (float)(short)(v & 0xFFFF), fy = (float)(v >> 16);
+                const float a = which == 2 ? fy : fx, b = which == 0 ? fx : fy;
+                acc = a * b + acc;                                   // two roundings (the file is built with -ffp-contract=off)
+            }
+        }
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < 3; sidx++) {
+        const float q0 = lane_f(acc, sidx * 8), q1 = lane_f(acc, sidx * 8 + 1), q2 = lane_f(acc, sidx * 8 + 2), q3 = lane_f(acc, sidx * 8 + 3);
+        const float t = lane_f(acc, sidx * 8 + 4);
+        As[sidx] = t + ((q0 + q2) + (q1 + q3));
+    }
+}
+// lds[xy * W * E + row * E + e] = diff * Ix (xy = 0) or diff * Iy (xy = 1), exact int32.  Chain lanes: lane = xy * 8 + c.
+template <int W, int CN>
+__device__ __forceinline__ void fs_sum_b(const int* __restrict__ lds, float& b1, float& b2) {
+    using F = LkFs<W, CN>;
+    const int lane = threadIdx.x & 63, c = lane & 7, xy = lane >> 3;
+    const int cnt = (xy < 2) ? (c < 4 ? F::NG : (c == 4 ? F::CNT_T : 0)) : 0;
+    const int e0 = c < 4 ? c : F::NSIMD, stride = c < 4 ? 8 : 1;
+    const int* P = lds + (xy & 1) * (W * F::E) + e0;
+    float acc = 0.f;
+    for (int y = 0; y < W; y++) {
+        const int* rp = P + y * F::E;
+#pragma unroll
+        for (int i = 0; i < F::MAXB; i++) {
+            if (i < cnt) {
+                int v = rp[i * stride];
+                if (c < 4) v += rp[i * stride + 4];                  // v_dotprod: element k with element k + 4, exact
+                acc += (float)v;
+            }
+        }
+    }
+    const float x0 = lane_f(acc, 0), x1 = lane_f(acc, 1), x2 = lane_f(acc, 2), x3 = lane_f(acc, 3), xt = lane_f(acc, 4);
+    const float y0 = lane_f(acc, 8), y1 = lane_f(acc, 9), y2 = lane_f(acc, 10), y3 = lane_f(acc, 11), yt = lane_f(acc, 12);
+    b1 = xt + ((x0 + x2) + (x1 + x3));
+    b2 = yt + ((y0 + y2) + (y1 + y3));
+}
+
 // One cv::calcOpticalFlowPyrLK track of a single point across all pyramid levels (LKTrackerInvoker semantics,
 // SURVEY.md Appendix A.3).  (px,py) -> (outx,outy), status.  Written as plain SIMT code: every "per feature" quantity
 // lives in a VGPR and is identical across the G lanes of the feature's group; control flow diverges between groups and
@@ -268,10 +345,13 @@ __device__ __forceinline__ void load_pairs(const uint8_t* __restrict__ p, unsign
 // CN = image channels: the window sums of LKTrackerInvoker run over every channel of every pixel (x < winSize.width*cn).
 // Each colour plane is its own single-channel pyramid (plane k at pyr + k * pstride); the (plane, segment) pairs a lane owns
 // are flattened into one index kk = plane * SPL + segment, so CN = 3 simply triples the per-lane pixel arrays.
-template <int W, int G, int CN>
+// FS = float-sums mode (above): fs_lds is the block's LkFs<W, CN>::LDS_INTS ints of LDS (unused otherwise).
+template <int W, int G, int CN, bool FS = false>
 __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, size_t pstride,
                         float px, float py, float& outx, float& outy, int& status, const LkCrit& crit,
-                        const LkSegs<LkLayout<W, G>::SPL>& sg, int& n_visits, int& n_steps) {
+                        const LkSegs<LkLayout<W, G>::SPL>& sg, int& n_visits, int& n_steps, int* fs_lds = nullptr) {
+    static_assert(!FS || G == 64, "the float-sums mode runs one feature per wave");
+    constexpr int FE = W * CN;                                          // interleaved elements per window row (float-sums mode)
     using LL = LkLayout<W, G>;
     constexpr int PPL = LL::PPL, EXT = LL::EXT, NS = LL::NS, NB = LL::NB, SPL = LL::SPL;
     constexpr int KS = SPL * CN;                                        // (plane, segment) pairs per lane
@@ -403,6 +483,9 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 const int ixacc = dot2(DXp[1][j], wd1, dot2(DXp[0][j], wd0, 1 << (LK_WBITS + 1)));
                 const int iyacc = dot2(DYp[1][j], wd1, dot2(DYp[0][j], wd0, 1 << (LK_WBITS + 1)));
                 ixv[j] = on ? ixacc : 0; iyv[j] = on ? iyacc : 0;
+                if constexpr (FS) {
+                    if (sg.on[k] && on) fs_lds[row * FE + (xs + j) * CN + kk / SPL] = (int)pack_hi16(ixacc, iyacc);
+                }
             }
 #pragma unroll
             for (int q = 0; q < NPR; q++) {
@@ -413,7 +496,11 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             }
         }
         float As[3];
-        {
+        if constexpr (FS) {
+            __syncthreads();
+            fs_sum_A<W, CN>(fs_lds, As);
+            __syncthreads();
+        } else {
             const int pa[3] = {pA11, pA12, pA22};
             // pA11, pA22 >= 0 and |pA12| <= (pA11 + pA22) / 2 per lane (|ab| <= (a^2 + b^2) / 2 term by term), so one unsigned
             // compare bounds all three partials: below 2^25 per lane the group sums stay inside int32 -> narrow reduction
@@ -504,12 +591,30 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 for (int q = 0; q < NPR; q++) {
                     // masked pixels (and the unpaired upper half) have Ix = Iy = 0: whatever mismatch they see contributes an exact zero
                     const unsigned dp = (2 * q + 1 < PPL) ? pack_lo16(dv[2 * q], dv[2 * q + 1]) : (unsigned)dv[2 * q];
+                    if constexpr (FS) {
+                        // per-element products diff * Ix, diff * Iy (exact int32) to LDS; the chain lanes sum them in OpenCV's order
+                        const int k = kk % SPL;
+                        const int xs = sg.xs[k];
+                        int* dst = fs_lds + sg.row[k] * FE + (xs + 2 * q) * CN + kk / SPL;
+                        const unsigned dlo = dp & 0xFFFFu, dhi = dp & 0xFFFF0000u;
+                        if (sg.on[k] && ((EXT == W) || (xs + 2 * q < W))) {
+                            dst[0] = dot2_keep(dlo, Ixp[kk][q], 0); dst[W * FE] = dot2_keep(dlo, Iyp[kk][q], 0);
+                        }
+                        if (2 * q + 1 < PPL && sg.on[k] && ((EXT == W) || (xs + 2 * q + 1 < W))) {
+                            dst[CN] = dot2_keep(dhi, Ixp[kk][q], 0); dst[W * FE + CN] = dot2_keep(dhi, Iyp[kk][q], 0);
+                        }
+                    } else {
                     if (kk == 0 && q == 0) { pb1 = dot2_keep(dp, Ixp[0][0], 0); pb2 = dot2_keep(dp, Iyp[0][0], 0); }   // no accumulator to clear first
                     else { pb1 = dot2(dp, Ixp[kk][q], pb1); pb2 = dot2(dp, Iyp[kk][q], pb2); }
+                    }
                 }
             }
             float bs[2];
-            {
+            if constexpr (FS) {
+                __syncthreads();
+                fs_sum_b<W, CN>(fs_lds, bs[0], bs[1]);
+                __syncthreads();
+            } else {
                 const int pb[2] = {pb1, pb2};
                 // narrow (int32 end to end) when the level's Cauchy-Schwarz bound allows it, or when this iteration's own
                 // partials are small: every lane |partial| < 2^25  =>  any sum over the <= 64 lanes of a group stays below 2^31
@@ -650,9 +755,10 @@ __device__ __forceinline__ LkCrit make_crit(const svo_config& c, float mineig_cu
 // Register budget: left to the compiler (w = 21: 104 VGPRs, four waves per SIMD).  Asking for a fifth wave (91 VGPRs, no
 // scratch) or for a third at w = 31 was measured on one box against this build and is not faster — 1 % slower at the
 // default two-context configuration, where the other kernels' waves have to fit beside LK's; a sixth wave spills.
-template <int W, int G, int CN>
-__global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mode, int chunk) {
+template <int W, int G, int CN, bool FS = false>
+__global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mode, int chunk, int early_out) {
     constexpr int FPW = 64 / G;                                       // features per wave (= per block)
+    __shared__ int fs_lds[FS ? LkFs<W, CN>::LDS_INTS : 1];            // float-sums mode only (the default build uses no LDS)
     int seq, fb;
     if (mode == LK_MAP_AFFINE) {
         const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
@@ -700,8 +806,11 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mo
         // Every pass's point is written out and folded into the masks as soon as it exists, so only the running point,
         // the start point and two flags stay live across the passes (fewer registers held through lk_pass).
         const bool writer = threadIdx.x % G == 0;
-        int allst = 1;
-        int inb = !((p0.x < 0) || (p0.y < 0) || (p0.y >= Hf) || (p0.x >= Wf));                        // vo.cpp:344-359, pointsLeftT0
+        // per-feature state across the passes, packed so that it holds ONE register through lk_pass (the kernel sits at the edge
+        // of its register budget: 104 VGPRs leave room for the other context's f64 kernels, svo_api.hip LkGate): bit 0 = every
+        // status so far is 1, bit 1 = every point so far lies inside the image, bits 2-3 = 1 + the first pass (0..2) that
+        // returned status 0 (0 = none)
+        int flags = 1 | ((!((p0.x < 0) || (p0.y < 0) || (p0.y >= Hf) || (p0.x >= Wf))) << 1);         // vo.cpp:344-359, pointsLeftT0
         float2 cur = p0;
         int n_visits = 0, n_steps = 0;                                 // svo_frame_stats.lk_level_visits / lk_newton_steps
         if (writer) d.pl0[o] = p0;
@@ -711,20 +820,27 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mo
             const uint8_t* Bq = pass == 0 ? L1 : pass == 1 ? R1 : pass == 2 ? R0 : L0;
             float2* out = pass == 0 ? d.pl1 : pass == 1 ? d.pr1 : pass == 2 ? d.pr0 : d.plc;
             float2 q; int st;
-            lk_pass<W, G, CN>(d.geom, A, Bq, (size_t)d.geom.pyr_bytes, cur.x, cur.y, q.x, q.y, st, crit, sg, n_visits, n_steps);
-            allst &= (st != 0);
-            if (pass < 3) inb &= !((q.x < 0) || (q.y < 0) || (q.y >= Hf) || (q.x >= Wf));          // pl1, pr1, pr0 (not the returned point)
+            lk_pass<W, G, CN, FS>(d.geom, A, Bq, (size_t)d.geom.pyr_bytes, cur.x, cur.y, q.x, q.y, st, crit, sg, n_visits, n_steps, fs_lds);
+            if (pass < 3 && ((q.x < 0) || (q.y < 0) || (q.y >= Hf) || (q.x >= Wf))) flags &= ~2;     // pl1, pr1, pr0 (not the returned point)
             if (writer) out[o] = q;
             cur = q;
+            // A feature whose status is 0 is deleted at vo.cpp:233-238 whatever the remaining passes return (the mask is the AND of
+            // the four statuses, vo.cpp:227-230): the frame pipeline stops here — nothing it reports can tell.  The member-call form
+            // (svo_circular_matching) hands the raw points of every pass to the caller and runs all four (early_out = 0).
+            if (st == 0) {
+                if ((flags & 1) && pass < 3) flags |= (pass + 1) << 2;
+                flags &= ~1;
+                if (early_out && pass < 3) { if constexpr (G == 64) { if (uni<G>(true)) break; } else if (FPW == 1) break; }
+            }
         }
         if (writer) {
             float ex = fabsf(p0.x - cur.x), ey = fabsf(p0.y - cur.y);
             float off = (ex < ey) ? ey : ex;
-            int circ = allst && !(off > thr);                                               // vo.cpp:227-230
-            d.okmask[o] = (uint8_t)(circ | (inb << 1));
+            int circ = (flags & 1) && !(off > thr);                                         // vo.cpp:227-230
+            d.okmask[o] = (uint8_t)(circ | (flags & 2));
             // work counters of svo_frame_stats: one plain store per feature, summed by k_compact (two atomicAdd per feature on
             // one address per sequence kept every wave's slot occupied until they drained: +14 % LK time, measured)
-            d.lk_work[o] = ((unsigned)n_steps << 8) | (unsigned)n_visits;
+            d.lk_work[o] = ((unsigned)n_steps << 8) | ((unsigned)(flags >> 2) << 6) | (unsigned)n_visits;
         }
     }
 }
@@ -767,6 +883,12 @@ static int lk_xcd_mapping() { static int v = -1; if (v < 0) { const char* e = ge
 #define LK_FOR_EACH_WINDOW_CN3(X) X(7, 16) X(7, 64) X(10, 16) X(10, 64) X(15, 32) X(15, 64) X(21, 64) X(5, 64) X(6, 64) X(8, 64) X(9, 64) X(11, 64) X(12, 64) X(13, 64) \
     X(14, 64) X(16, 64) X(17, 64) X(18, 64) X(19, 64) X(20, 64)
 
+// float-sums builds (svo_config.lk_float_sums): one feature per wave at every window
+#define LK_FOR_EACH_WINDOW_FS(X) X(5, 64) X(6, 64) X(7, 64) X(8, 64) X(9, 64) X(10, 64) X(11, 64) X(12, 64) X(13, 64) X(14, 64) X(15, 64) X(16, 64) X(17, 64) \
+    X(18, 64) X(19, 64) X(20, 64) X(21, 64) X(22, 64) X(23, 64) X(24, 64) X(25, 64) X(26, 64) X(27, 64) X(28, 64) X(29, 64) X(30, 64) X(31, 64)
+#define LK_FOR_EACH_WINDOW_FS_CN3(X) X(5, 64) X(6, 64) X(7, 64) X(8, 64) X(9, 64) X(10, 64) X(11, 64) X(12, 64) X(13, 64) X(14, 64) X(15, 64) X(16, 64) X(17, 64) \
+    X(18, 64) X(19, 64) X(20, 64) X(21, 64)
+
 // Smallest float x with (double)(float)(x / (2 w^2)) >= threshold — found by bisection over the floats in their numeric order
 // (IEEE f32 division on the host, the same operation the kernel would do).  +inf if no finite float qualifies.
 float lk_mineig_cut(int win, double threshold) {
@@ -799,12 +921,15 @@ bool lk_window_supported_cn(int win, int cn) {
 // KITTI-sized frames with ~2 000 features (LK time per frame, 64 lanes vs grouped): w = 10: 111 vs 239 us at 1 sequence, 285 vs
 // 411 at 8, 1 809 vs 1 954 at 64; w = 15: 135 vs 213, 363 vs 458, 2 375 vs 2 676.  A grouped wave runs until its slowest feature
 // is done and cannot branch per feature.  The grouped builds stay selectable (SVO_LK_G=16 / 32) for measurement.
-static int lk_group_for(int win) {
+// cn selects the list the answer must come from: a lanes-per-feature value asked for with SVO_LK_G is honoured only if that
+// (window, lanes) pair is built for this channel count, else the window's default applies (a 3-channel context with
+// SVO_LK_G=32 at w = 21 used to match no instantiation and launch nothing).
+static int lk_group_for(int win, int cn = 1) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("SVO_LK_G"); env = e ? atoi(e) : 0; }
     int def = 0; bool have_env = false, have64 = false;
 #define CHK(Wn, Gn) if (win == Wn) { if (!def) def = Gn; if (env == Gn) have_env = true; if (Gn == 64) have64 = true; }
-    LK_FOR_EACH_WINDOW(CHK)
+    if (cn == 3) { LK_FOR_EACH_WINDOW_CN3(CHK) } else { LK_FOR_EACH_WINDOW(CHK) }
 #undef CHK
     return have_env ? env : have64 ? 64 : def;
 }
@@ -813,16 +938,19 @@ static int lk_group_for(int win) {
 // waves): the 96-register builds of the f64 kernels (svo_kernels_pnp.hip) can run under another context's LK grid only if this
 // is >= 96 — true at w = 21 (100 registers: four waves, 96 left) and 31, not at w = 10 (74: six waves, 32 left).  -1 if unknown.
 int lk_registers_left(const DevBuffers& d) {
-    const int G = lk_group_for(d.cfg.win_w);
+    const bool fs = d.cfg.lk_float_sums != 0;
+    const int G = fs ? 64 : lk_group_for(d.cfg.win_w, d.CN);
     const void* fn = nullptr;
-#define PICK(Wn, Gn) if (!fn && d.cfg.win_w == Wn && G == Gn) fn = (const void*)k_lk_chain<Wn, Gn, CNn>;
+#define PICK(Wn, Gn) if (!fn && !fs && d.cfg.win_w == Wn && G == Gn) fn = (const void*)k_lk_chain<Wn, Gn, CNn>;
+#define PICKFS(Wn, Gn) if (!fn && fs && d.cfg.win_w == Wn) fn = (const void*)k_lk_chain<Wn, 64, CNn, true>;
 #define CNn 1
-    if (d.CN == 1) { LK_FOR_EACH_WINDOW(PICK) }
+    if (d.CN == 1) { LK_FOR_EACH_WINDOW(PICK) LK_FOR_EACH_WINDOW_FS(PICKFS) }
 #undef CNn
 #define CNn 3
-    if (d.CN == 3) { LK_FOR_EACH_WINDOW_CN3(PICK) }
+    if (d.CN == 3) { LK_FOR_EACH_WINDOW_CN3(PICK) LK_FOR_EACH_WINDOW_FS_CN3(PICKFS) }
 #undef CNn
 #undef PICK
+#undef PICKFS
     hipFuncAttributes at;
     if (!fn || hipFuncGetAttributes(&at, fn) != hipSuccess || at.numRegs <= 0) return -1;
     const int alloc = (at.numRegs + 7) / 8 * 8;
@@ -830,18 +958,36 @@ int lk_registers_left(const DevBuffers& d) {
     return 512 - waves * alloc;
 }
 
-void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
+bool launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st, int early_out) {
     if (grid_n < 1) grid_n = 1;
     if (grid_n > d.CAP) grid_n = d.CAP;
-    const int G = lk_group_for(d.cfg.win_w);
+    const bool fs = d.cfg.lk_float_sums != 0;
+    const int G = fs ? 64 : lk_group_for(d.cfg.win_w, d.CN);
     const int mode = lk_xcd_mapping();
+    if (fs) {
+#define LAUNCHFS(Wn, Gn) if (d.cfg.win_w == Wn) { int gx = grid_n; if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
+        const int chunk = lk_chunk(); \
+        gx = (gx + 8 * chunk - 1) / (8 * chunk) * (8 * chunk); \
+        const int rounds = (d.B + 7) / 8; \
+        const unsigned blocks = mode == LK_MAP_AFFINE ? (unsigned)gx * 8u * (unsigned)rounds : (unsigned)gx * (unsigned)d.B; \
+        hipLaunchKernelGGL((k_lk_chain<Wn, 64, CNn, true>), dim3(blocks), dim3(64), 0, st, d, gx, mode, chunk, early_out); \
+        return true; }
+#define CNn 1
+        if (d.CN == 1) { LK_FOR_EACH_WINDOW_FS(LAUNCHFS) }
+#undef CNn
+#define CNn 3
+        if (d.CN == 3) { LK_FOR_EACH_WINDOW_FS_CN3(LAUNCHFS) }
+#undef CNn
+#undef LAUNCHFS
+        return false;
+    }
 #define LAUNCH(Wn, Gn) if (d.cfg.win_w == Wn && G == Gn) { int gx = (grid_n + (64 / Gn) - 1) / (64 / Gn); if (gx > LK_MAX_GRID) gx = LK_MAX_GRID; \
         const int chunk = lk_chunk(); \
         gx = (gx + 8 * chunk - 1) / (8 * chunk) * (8 * chunk);   /* blocks per sequence: whole runs on every XCD */ \
         const int rounds = (d.B + 7) / 8; \
         const unsigned blocks = mode == LK_MAP_AFFINE ? (unsigned)gx * 8u * (unsigned)rounds : (unsigned)gx * (unsigned)d.B; \
-        hipLaunchKernelGGL((k_lk_chain<Wn, Gn, CNn>), dim3(blocks), dim3(64), 0, st, d, gx, mode, chunk); \
-        return; }
+        hipLaunchKernelGGL((k_lk_chain<Wn, Gn, CNn>), dim3(blocks), dim3(64), 0, st, d, gx, mode, chunk, early_out); \
+        return true; }
 #define CNn 1
     if (d.CN == 1) { LK_FOR_EACH_WINDOW(LAUNCH) }
 #undef CNn
@@ -852,10 +998,11 @@ void launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t st) {
         gx = (gx + 8 * chunk - 1) / (8 * chunk) * (8 * chunk); \
         const int rounds = (d.B + 7) / 8; \
         const unsigned blocks = mode == LK_MAP_AFFINE ? (unsigned)gx * 8u * (unsigned)rounds : (unsigned)gx * (unsigned)d.B; \
-        hipLaunchKernelGGL((k_lk_chain<Wn, Gn, 3>), dim3(blocks), dim3(64), 0, st, d, gx, mode, chunk); \
-        return; }
+        hipLaunchKernelGGL((k_lk_chain<Wn, Gn, 3>), dim3(blocks), dim3(64), 0, st, d, gx, mode, chunk, early_out); \
+        return true; }
     if (d.CN == 3) { LK_FOR_EACH_WINDOW_CN3(LAUNCH3) }
 #undef LAUNCH3
+    return false;                                                     // no (window, lanes, channels) instantiation: the caller reports it
 }
 
 void launch_lk_single(const DevBuffers& d, int slotA, int camA, int slotB, int camB, int n, const float2* prev, float2* next,

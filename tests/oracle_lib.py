@@ -32,13 +32,15 @@ class OrcConfig(C.Structure):
         ("max_translation_norm", C.c_double), ("max_rotation_norm", C.c_double),
         ("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int), ("lk_max_count", C.c_int),
         ("lk_epsilon", C.c_double), ("ransac_confidence", C.c_float), ("max_features", C.c_int), ("channels", C.c_int),
+        ("lk_float_sums", C.c_int),
     ]
 
 
 class OrcFrameStats(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "n_after_detect", "second_pass", "n_into_lk", "n_after_circular", "n_after_bounds",
-        "n_inliers", "ransac_iters", "fail_reason", "n_features_out", "lk_level_visits", "lk_newton_steps")]
+        "n_inliers", "ransac_iters", "fail_reason", "n_features_out", "lk_level_visits", "lk_newton_steps",
+        "lk_dead_after_pass0", "lk_dead_after_pass1", "lk_dead_after_pass2")]
 
 
 ORC_MAX_LEVELS = 8

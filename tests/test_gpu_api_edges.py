@@ -185,6 +185,20 @@ def test_graph_replay_equals_the_launch_list(api, monkeypatch):
     assert sum(r[0] for r in outs["1"]) >= 9
 
 
+def test_lk_kernel_leaves_room_for_the_other_contexts_kernels(api):
+    """The default LK build at the metric's 21x21 window must stay at <= 104 registers (four waves per SIMD, 96 registers left):
+    only then do two many-sequence contexts overlap one's f64 kernels with the other's LK kernel — a change to the
+    kernel that costs this silently costs the bench 2-3 % and makes the roofline's per-launch duration meaningless."""
+    from stereo_visual_odometry_amd._lib import lib
+    lib.svo_get_lk_registers_left.restype = C.c_int
+    lib.svo_get_lk_registers_left.argtypes = [C.c_void_p]
+    for win, want in ((21, 96), (31, 96)):
+        vo = api.BatchVisualOdometry(1241, 376, 1, api.default_config(win_w=win, win_h=win))
+        left = lib.svo_get_lk_registers_left(vo._h)
+        assert left >= want, (win, left)
+        vo.close()
+
+
 def test_set_projection_per_sequence_and_all(api):
     """svo_set_projection(seq = -1) writes every sequence's record, seq = k only that one (one strided copy either way):
     a batch whose sequences get DIFFERENT baselines returns different translations for the same images."""

@@ -5,6 +5,8 @@ compared bit-for-bit too (the LK arithmetic is exact-integer + IEEE f32); poses 
 """
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -255,6 +257,30 @@ def test_stage_calls_reuse_their_device_buffers_and_stay_exact(api):
     t = threading.Thread(target=other); t.start(); t.join()
     assert not err, err
     run(cases[0])
+    # short-lived worker threads: each one's cached context goes back to a registry when the thread ends and is taken over by
+    # the next thread (round-2 advisor finding: one leaked context of GPU memory per thread); clear_all frees what is left
+    lib.svo_stage_cache_clear_all.restype = C.c_int
+
+    def worker(case):
+        try:
+            run(case); run(case)
+        except BaseException as e:                                 # noqa: BLE001
+            err.append(e)
+    for k in range(6):
+        t = threading.Thread(target=worker, args=(cases[k % 2],)); t.start(); t.join()
+    assert not err, err
+    assert lib.svo_stage_cache_clear_all() <= 2                    # this thread's + ONE orphan shared by all six workers, not six
+    assert lib.svo_stage_cache_clear_all() == 0
+    run(cases[1])
+    # parameters that do not shape the buffers are taken over in place: alternating them must not change results
+    K = np.eye(3, dtype=np.float32)
+    rng = np.random.default_rng(3)
+    world = rng.uniform(-1, 1, (40, 3)).astype(np.float32) + np.array([0, 0, 4], np.float32)
+    cam = (world[:, :2] / world[:, 2:3]).astype(np.float32)
+    for it, conf in ((100, 0.98), (50, 0.9), (100, 0.98), (20, 0.999)):
+        (inl_g, ok_g), R_g, t_g, _ = api.cameraToWorld(K, cam, world, np.eye(3), np.zeros(3), iterations=it, confidence=conf)
+        ok_o, R_o, t_o, inl_o, _ = orc.camera_to_world(K, cam, world, np.eye(3), np.zeros(3), iterations=it, confidence=conf)
+        assert ok_g == ok_o and np.array_equal(inl_g, inl_o) and np.abs(R_g - R_o).max() < 1e-9 and np.abs(t_g.reshape(3) - t_o).max() < 1e-9
 
 
 @pytest.mark.parametrize("win", [w for w in range(5, 32) if w not in (7, 10, 15, 21, 31)])
@@ -582,6 +608,41 @@ def test_stereo_callback_sequence_parity(api, win, lv):
     assert all(r[0] for r in res[1:])
     gt = seq.relative_motion(2)
     assert np.abs(res[2][1][:3, 3] - gt[:3, 3]).max() < 0.03
+
+
+@pytest.mark.parametrize("win,lv", [(10, 3), (21, 3), (7, 2), (13, 3), (31, 2)])
+def test_float_sums_mode_parity(api, win, lv):
+    """svo_config.lk_float_sums = 1: the LK sums in FLOAT, in the lane order of OpenCV's SIMD128 code (oracle: deviation D1
+    reverted, orc_config.lk_float_sums).  Same bar as the default mode: every counter, feature set, track list, world point
+    and inlier mask bit-exact — and the two modes must really differ somewhere (or the switch does nothing)."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=480, height=200, cx=240.0, cy=100.0)
+    seq = syn.StereoSequence(cal=cal, n_frames=5, seed=12, step=0.4)
+    over = dict(win_w=win, win_h=win, max_level=lv, max_translation_norm=2.0)
+    fs = run_both(api, seq, dict(over, lk_float_sums=1), 5)
+    assert all(r[0] for r in fs[1:])
+    ex = run_both(api, seq, over, 5)
+    assert any(not np.array_equal(a[1], b[1]) for a, b in zip(fs[1:], ex[1:])), "float sums and exact sums gave identical poses"
+    assert max(np.abs(a[1] - b[1]).max() for a, b in zip(fs[1:], ex[1:])) < 1e-3
+
+
+def test_float_sums_mode_kitti_frame_and_batch(api):
+    """full cfg2-sized frames in float-sums mode, as a batch of two sequences (different frames) against two oracle objects"""
+    from stereo_visual_odometry_amd import synthetic as syn
+    seq = syn.StereoSequence(n_frames=4, seed=0x5EED0002)
+    Pl, Pr = syn.projection_matrices(seq.cal)
+    over = dict(win_w=21, win_h=21, max_level=3, max_translation_norm=2.0, lk_float_sums=1)
+    b = api.BatchVisualOdometry(seq.cal["width"], seq.cal["height"], 2, api.default_config(**over)); b.initalize_projection_matricies(Pl, Pr)
+    os_ = []
+    for _ in range(2):
+        o = orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl, Pr); os_.append(o)
+    for k in range(3):
+        ok, T = b.stereo_callback_batch([seq.left[k], seq.left[k + 1]], [seq.right[k], seq.right[k + 1]])
+        for i, o in enumerate(os_):
+            ok_o, T_o = o.stereo_callback(seq.left[k + i], seq.right[k + i])
+            so = {f[0]: getattr(o.stats, f[0]) for f in o.stats._fields_}
+            assert bool(ok[i]) == ok_o and so == b.stats[i].as_dict(), (k, i, so, b.stats[i].as_dict())
+            assert np.abs(T[i] - T_o).max() < 1e-6
 
 
 def test_stereo_callback_failure_paths_parity(api):

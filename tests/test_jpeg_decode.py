@@ -107,3 +107,58 @@ def test_cli_replays_a_jpeg_folder_with_four_digit_names(tmp_path):
         ok, T = vo.stereo_callback(bgr(folder / "left" / ("frame%04d.jpg" % k)), bgr(folder / "right" / ("frame%04d.jpg" % k)))
         pose = pose @ T; track.append(pose[:3, 3].copy())
     assert np.abs(rows[:, :3] - np.array(track)).max() < 1e-8        # the CSV prints 9 significant digits
+    # ... and of the CPU ORACLE fed the PIL-decoded frames (round-2 verdict: the comparison above is HIP against HIP): flags and
+    # counters identical frame by frame, the CLI's rows within 1e-6 m of the oracle trajectory (as test_run1_cli does for PNG)
+    import oracle_lib as orc
+    ovo = orc.VisualOdometry(orc.default_config()); ovo.initalize_projection_matricies(*syn.projection_matrices(cal))
+    gvo = api.VisualOdometry(); gvo.initalize_projection_matricies(*syn.projection_matrices(cal))
+    pose, otrack = np.eye(4), []
+    for k in range(6):
+        bgr = lambda p: np.ascontiguousarray(np.asarray(PIL_Image.open(p).convert("RGB"))[..., ::-1])
+        L, R = bgr(folder / "left" / ("frame%04d.jpg" % k)), bgr(folder / "right" / ("frame%04d.jpg" % k))
+        ok_o, T_o = ovo.stereo_callback(L, R)
+        ok_g, _ = gvo.stereo_callback(L, R)
+        assert ok_o == ok_g and {f[0]: getattr(ovo.stats, f[0]) for f in ovo.stats._fields_} == gvo.stats.as_dict(), k
+        pose = pose @ T_o; otrack.append(pose[:3, 3].copy())
+    assert np.abs(rows[:, :3] - np.array(otrack)).max() < 1e-6
+
+
+def test_malformed_files_under_the_sanitizers(tmp_path):
+    """Truncated and corrupted files (table selectors out of range, SOF / SOS segments cut short, random byte flips) must be
+    refused or decoded without touching memory they do not own: the decoder is built with -fsanitize=address,undefined (CPU
+    build only) and run over a few hundred mutations — any report aborts the child."""
+    exe = os.path.join(ROOT, "tools", "jpeg_to_raw_asan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I" + os.path.join(ROOT, "tools"), os.path.join(ROOT, "tools", "jpeg_to_raw.cpp"), "-o", exe])
+    rng = np.random.default_rng(7)
+    base = []
+    for name, sub in (("a", 0), ("b", 2)):
+        p = os.path.join(tmp_path, name + ".jpg")
+        PIL_Image.fromarray(images()["gradients"]).save(p, quality=85, subsampling=sub)
+        base.append(open(p, "rb").read())
+    PIL_Image.fromarray(images()["gradients"][..., 0]).save(os.path.join(tmp_path, "g.jpg"), quality=85)
+    base.append(open(os.path.join(tmp_path, "g.jpg"), "rb").read())
+    cases = []
+    for b in base:
+        sos = b.index(b"\xff\xda"); sof = b.index(b"\xff\xc0")
+        for cut in (3, sof + 3, sof + 7, sof + 9, sos + 3, sos + 5, sos + 8, len(b) // 2, len(b) - 3):
+            cases.append(b[:cut])
+        ns = b[sos + 4]
+        for i in range(ns):                                          # table selectors 0..15 where only 0..3 exist
+            m = bytearray(b); m[sos + 6 + 2 * i] = 0xFF; cases.append(bytes(m))
+        m = bytearray(b); m[sof + 9] = 9; cases.append(bytes(m))      # component count
+        m = bytearray(b); m[sos + 2:sos + 4] = b"\x00\x03"; cases.append(bytes(m))   # SOS length shorter than its content
+        for _ in range(60):                                          # random flips in the headers and in the entropy-coded data
+            m = bytearray(b)
+            for _k in range(int(rng.integers(1, 6))):
+                m[int(rng.integers(2, len(m)))] = int(rng.integers(0, 256))
+            cases.append(bytes(m))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    bad = 0
+    for i, c in enumerate(cases):
+        p = os.path.join(tmp_path, "m%d.jpg" % i)
+        open(p, "wb").write(c)
+        r = subprocess.run([exe, p, os.path.join(tmp_path, "o.raw")], capture_output=True, env=env, timeout=60)
+        assert r.returncode in (0, 1), (i, r.returncode, r.stderr[-400:])    # decoded, or refused cleanly; never a sanitizer abort
+        bad += r.returncode == 1
+    assert bad > 20

@@ -164,6 +164,7 @@ inline Image decode(const uint8_t* data, size_t size) {
                 p += 16 + total;
             }
         } else if (m == 0xC0 || m == 0xC1) {
+            if (seg + 6 > end) return img;                              // precision, height, width, component count must lie inside the segment
             if (data[seg] != 8) return img;
             H = be16(seg + 1); W = be16(seg + 3);
             int nc = data[seg + 5];
@@ -177,17 +178,20 @@ inline Image decode(const uint8_t* data, size_t size) {
         } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8)) {
             return img;                                                 // progressive / lossless / arithmetic: not handled
         } else if (m == 0xDD) {
+            if (seg + 2 > end) return img;
             restart = be16(seg);
         } else if (m == 0xE0) {
             if (len >= 7 && !memcmp(data + seg, "JFIF", 5)) jfif = true;
         } else if (m == 0xEE) {
             if (len >= 14 && !memcmp(data + seg, "Adobe", 5)) adobe_transform = data[seg + 11];
         } else if (m == 0xDA) {
-            if (comps.empty()) return img;
+            if (comps.empty() || seg + 1 > end) return img;
             int ns = data[seg];
             if (ns != (int)comps.size()) return img;                    // baseline files are one interleaved scan
+            if (seg + 1 + 2 * ns + 3 > end) return img;                 // component selectors + Ss, Se, Ah/Al must lie inside the segment
             for (int i = 0; i < ns; i++) {
                 int cid = data[seg + 1 + 2 * i], tt = data[seg + 2 + 2 * i];
+                if ((tt >> 4) > 3 || (tt & 15) > 3) return img;         // table selectors index dc[4] / ac[4]
                 bool found = false;
                 for (auto& c : comps) if (c.id == cid) { c.td = tt >> 4; c.ta = tt & 15; found = true; }
                 if (!found) return img;

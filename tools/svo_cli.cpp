@@ -2,6 +2,7 @@
 // 315-407) on top of the C++ facade / C-ABI.  SURVEY.md §8 f-1.
 //
 //   svo_cli <N_FRAMES> <folder> [--calib file.yaml] [--out result.csv] [--device d] [--gray 1] [--identity-start 1]
+//                               [--float-sums 1] [--ref-format 1]
 //
 // Reads folder/left/frameNNNNNN.{pgm,png,jpg} (6 digits, as `run1`) or frameNNNN.{jpg,png,pgm} (4 digits, as the reference's
 // other two bundled sets slam_feats/ and rand_feats/, which its current CLI cannot open; tools/jpeg_decode.hpp) and
@@ -13,6 +14,9 @@
 // cv::cvtColor BGR2GRAY integer formula and runs the single-channel path instead (what the ROS node delivers).
 // `--identity-start 1` starts from the identity pose: the bundled run1/result.csv was recorded that way (it predates the
 // 26-degree pitch of main.cpp:368-373), and with it this tool reproduces that file (tests/test_run1_color.py).
+// `--float-sums 1` selects svo_config.lk_float_sums (LK sums in float, in the lane order of OpenCV's SIMD128 code) and
+// `--ref-format 1` prints the rows like the reference's ofstream does (6 significant digits, main.cpp:397-400): together with
+// `--identity-start 1` the tool then writes run1/result.csv's x,y,z columns digit for digit (tests/test_run1_color.py).
 // Differences, on purpose:
 //   * the run stops cleanly at the first missing image pair (the reference throws on run1's frame 128, B-12);
 //   * calibration may come from a YAML file with either key style (stereo_vo.cpp:40-44 `fx:` or kitti00.yaml `Camera.fx:`);
@@ -157,14 +161,16 @@ static void matmul4(const double* A, const double* B, double* C) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s <N_FRAMES> <folder> [--calib file.yaml] [--out result.csv] [--device d] [--gray 1] [--identity-start 1]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s <N_FRAMES> <folder> [--calib file.yaml] [--out result.csv] [--device d] [--gray 1] [--identity-start 1] [--float-sums 1] [--ref-format 1]\n", argv[0]); return 2; }
     const int N_FRAMES = std::atoi(argv[1]);
     const std::string folder = argv[2];
     std::string calib, out = folder + "/result.csv";
-    bool gray = false, identity_start = false;
+    bool gray = false, identity_start = false, float_sums = false, ref_format = false;
     for (int i = 3; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--gray")) gray = std::atoi(argv[i + 1]) != 0;
         else if (!strcmp(argv[i], "--identity-start")) identity_start = std::atoi(argv[i + 1]) != 0;
+        else if (!strcmp(argv[i], "--float-sums")) float_sums = std::atoi(argv[i + 1]) != 0;
+        else if (!strcmp(argv[i], "--ref-format")) ref_format = std::atoi(argv[i + 1]) != 0;
         else if (!strcmp(argv[i], "--calib")) calib = argv[i + 1];
         else if (!strcmp(argv[i], "--out")) out = argv[i + 1];
         else if (!strcmp(argv[i], "--device")) default_device() = std::atoi(argv[i + 1]);
@@ -181,7 +187,9 @@ int main(int argc, char** argv) {
     if (!res) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 2; }
     res << "x,y,z,gtx,gty\n";
     try {
-        VisualOdometry vo;
+        svo_config cfg; svo_config_default(&cfg);
+        cfg.lk_float_sums = float_sums ? 1 : 0;
+        VisualOdometry vo(cfg);
         vo.initalize_projection_matricies(Pl, Pr);
         const double theta = (26.0 / 360) * 2 * M_PI;                                                    // main.cpp:368-373
         double pose[16] = {1, 0, 0, 0, 0, cos(theta), sin(theta), 0, 0, -sin(theta), cos(theta), 0, 0, 0, 0, 1};
@@ -200,7 +208,7 @@ int main(int argc, char** argv) {
                           : vo.stereo_callback(Image(l.bgr.data(), l.h, l.w, 0, 3), Image(r.bgr.data(), r.h, r.w, 0, 3));
             matmul4(pose, o.second.data(), pose);                                                         // applied even when !ok (main.cpp:394-396)
             char row[256];
-            std::snprintf(row, sizeof(row), "%.9g,%.9g,%.9g,%.9g,%.9g\n", pose[3], pose[7], pose[11], gtx, gty);
+            std::snprintf(row, sizeof(row), ref_format ? "%g,%g,%g,%g,%g\n" : "%.9g,%.9g,%.9g,%.9g,%.9g\n", pose[3], pose[7], pose[11], gtx, gty);
             res << row;
             std::printf("Frame %d: ok=%d tracks=%d inliers=%d\n", i, (int)o.first, vo.stats.n_after_bounds, vo.stats.n_inliers);
             done++;
