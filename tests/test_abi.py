@@ -94,3 +94,24 @@ def test_channel_arguments_are_validated_before_any_device_work():
         h = C.c_void_p()
         rc = _lib.lib.svo_create(C.byref(cfg), 0, 1, 640, 480, C.byref(h))
         assert rc == _lib.SVO_ERR_ARG and expect in _lib.lib.svo_last_error().decode() and not h.value
+
+
+# ---------------------------------------------------------------------------- libsvo_rccl.so (include/svo_gather.h)
+def _gather_header_symbols():
+    import re
+    txt = open(os.path.join(ROOT, "include", "svo_gather.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(svo_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_gather_library_exports_every_declared_symbol():
+    """include/svo_gather.h <-> libsvo_rccl.so (no GPU needed: loading and symbol lookup only)"""
+    lib = C.CDLL(os.path.join(ROOT, "stereo_visual_odometry_amd", "libsvo_rccl.so"))
+    syms = _gather_header_symbols()
+    assert syms == ["svo_gather_last_error", "svo_gather_pose_streams", "svo_gather_pose_streams_ragged"]
+    for s in syms:
+        assert hasattr(lib, s), s
+    # and the core library stays free of RCCL: a single-GPU integration never loads it
+    import subprocess
+    deps = subprocess.run(["ldd", os.path.join(ROOT, "stereo_visual_odometry_amd", "libsvo_hip.so")], capture_output=True, text=True).stdout
+    assert "rccl" not in deps

@@ -76,3 +76,20 @@ def test_bench_two_ranks_end_to_end_on_one_gpu_gloo():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["sequences_per_gpu"] == 8 and line["config"]["pose_ok_fraction"] > 0.9
     assert abs(line["value"] - 2 * 8 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]     # whole-job rate over both ranks
+
+
+# ---------------------------------------------------------------------------- the C entry of the exchange (libsvo_rccl.so)
+@pytest.mark.gpu
+def test_c_entry_of_the_pose_gather_on_a_one_device_communicator():
+    """a C / C++ host that drives the GPUs from one process gathers its pose streams through
+    svo_gather_pose_streams (ncclCommInitAll + grouped ncclSend / ncclRecv).  The test box has one GPU: a 1-device communicator
+    (the N-device run is the driver's, like every N > 1 run); plain g++, no torch, no Python in the child."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "gather_gpu_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "gather_gpu_test.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "stereo_visual_odometry_amd"), "-lsvo_rccl",
+                           "-Wl,-rpath," + os.path.join(ROOT, "stereo_visual_odometry_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "GATHER OK 1" in out.stdout, out.stdout + out.stderr

@@ -1,13 +1,43 @@
-# The round-2 collection: kernel stats at 32 / 1 / 256 sequences under rocprofv3, the bench lines, the latency figures.
-# usage (MI355X box): bash tools/collect_profiles.sh   -> gpurun_out/r02f/ ; the files are then copied into profiles/ (profiles/README.md)
+# One-call collection of a round's rocprofv3 evidence (MI355X box):  bash tools/collect_profiles.sh r03
+#   -> gpurun_out/<tag>p/ ; then, in the build container:  bash tools/collect_profiles.sh r03 --summarize   copies / reduces into profiles/
+# Kernel stats at 32 / 1 / 256 sequences, the counter passes (FETCH_SIZE, WRITE_SIZE, two SQ passes, GRBM_GUI_ACTIVE — one --pmc
+# pass each, with --kernel-trace only) at the DEFAULT bench configuration (two contexts of 128 sequences: the launch the bench
+# line's roofline is about), the bench lines and the latency figures.
 set -e
+TAG=${1:-r03}
+if [ "$2" = "--summarize" ]; then
+  O=gpurun_out/${TAG}p
+  python3 profiles/summarize.py ${TAG} $O/s32 $O/fetch $O/write --seqs 128
+  python3 profiles/summarize.py ${TAG} --sq $O/sq1 --bench $O/bench.json --extra $O/sq2 --gui $O/gui
+  cp $(find $O/s256 -name '*kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats_256seq_2ctx.csv
+  cp $(find $O/s1 -name '*kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats_1seq.csv
+  cp $(find $O/s1s -name '*kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats_1seq_static.csv
+  cp $O/bench.json profiles/${TAG}_bench.json; cp $O/bench_static.json profiles/${TAG}_bench_static.json
+  tail -1 $O/s32.log > profiles/${TAG}_bench_32seq_1ctx.json; tail -1 $O/s256.log > profiles/${TAG}_bench_256seq_under_rocprof.json
+  cp $O/latency.txt profiles/${TAG}_latency.txt
+  exit 0
+fi
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02f; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/s32 -o s32 -- python3 bench.py --steps 20 --warmup 4 --cpu-frames 0 --seqs 32 --contexts 1 > $O/s32.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/s1 -o s1 -- python3 bench.py --seqs 1 --contexts 1 --depth 1 --steps 40 --cpu-frames 0 > $O/s1.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/s1s -o s1s -- python3 bench.py --seqs 1 --contexts 1 --depth 1 --steps 40 --cpu-frames 0 --movers 0 > $O/s1s.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/s256 -o s256 -- python3 bench.py --steps 20 --warmup 4 --cpu-frames 0 > $O/s256.log 2>&1
+O=gpurun_out/${TAG}p; mkdir -p $O
+B="python3 bench.py --steps 20 --warmup 4 --cpu-frames 0 --ate-frames 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/s32 -o s32 -- $B --seqs 32 --contexts 1 > $O/s32.log 2>&1
+echo s32 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/s1 -o s1 -- python3 bench.py --seqs 1 --contexts 1 --depth 1 --steps 40 --cpu-frames 0 --ate-frames 0 > $O/s1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/s1s -o s1s -- python3 bench.py --seqs 1 --contexts 1 --depth 1 --steps 40 --cpu-frames 0 --ate-frames 0 --movers 0 > $O/s1s.log 2>&1
+echo s1 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/s256 -o s256 -- $B > $O/s256.log 2>&1
+echo s256 done
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- $B > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- $B > $O/write.log 2>&1
+echo hbm counters done
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD --output-format csv -d $O/sq1 -o sq1 -- $B > $O/sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --output-format csv -d $O/sq2 -o sq2 -- $B > $O/sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/gui -o gui -- $B > $O/gui.log 2>&1
+echo sq counters done
 python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 bench.py --movers 0 --cpu-frames 0 > $O/bench_static.json 2> $O/bench_static.err
 python3 tools/measure_pcie.py > $O/latency.txt 2>&1
 python3 tools/stage_latency.py >> $O/latency.txt 2>&1
+# keep what travels back small: the per-dispatch traces are large, the summaries and counter CSVs are what profiles/ needs
+find $O -name '*kernel_trace.csv' -size +8M -delete || true
+du -sh $O
