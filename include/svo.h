@@ -16,6 +16,7 @@
  */
 #ifndef SVO_H
 #define SVO_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -111,6 +112,14 @@ int svo_set_projection(svo_context* ctx, int seq, const float Pl[12], const floa
  * ok_out: n_seq ints: the pair's .first.  stats: n_seq entries or NULL. */
 int svo_process_batch(svo_context* ctx, const uint8_t* const* left, const uint8_t* const* right, int stride,
                       int images_on_device, double* T_out, int* ok_out, svo_frame_stats* stats);
+
+/* Page-locked host memory for the caller's image buffers (hipHostMalloc underneath; any hipHostMalloc'ed / hipHostRegister'ed
+ * memory works the same).  svo_process / svo_process_batch given host images COPY them first (SURVEY.md 8b "Ownership": inputs
+ * are borrowed for the call only); images that lie in page-locked memory with packed rows (stride == width * channels) are read
+ * by the DMA engines in place, which saves the staging memcpy — ~40 us per 1241x376 pair, 0.54 -> 0.50 ms per synchronous call.
+ * The reference has no counterpart (cv::Mat data is ordinary heap memory). */
+void* svo_alloc_pinned(size_t bytes);
+void  svo_free_pinned(void* p);
 
 /* n_seq == 1 convenience with the reference's callback shape (also the ROS-callback shape, src/stereo_vo.cpp:61-62).
  * Returns 1 (pose produced), 0 (no pose this frame; T_out = last good transform) or a negative svo_status. */

@@ -108,6 +108,9 @@ int orc_set_threads(int n);
 #define ORC_OCV_D4_RVEC_TRIP     0x08u  /* hypotheses stored as rvec|tvec: scoring goes R -> rvec -> R through cv::Rodrigues */
 #define ORC_OCV_D5_JACOBI_CYCLIC 0x10u  /* EPnP's 12x12 Jacobi SVD sweeps cyclic-by-rows (JacobiSVDImpl_) */
 #define ORC_OCV_HYPOT            0x20u  /* every Jacobi rotation computes gamma = hypot(p, beta) with libm, as JacobiSVDImpl_ does (oracle: sqrt(p*p + beta*beta)) */
+#define ORC_ALT_J12_HALVES       0x1000u /* experiment: the 12-term sums of EPnP's 12x12 Jacobi as two halves (lane-parallel form) */
+#define ORC_ALT_J12_QUARTERS     0x2000u /* experiment: ... as four quarters of three */
+#define ORC_ALT_TRI_RR           0x4000u /* experiment: the 4x4 Jacobi of the triangulation sweeps in round-robin order */
 #define ORC_OCV_D1_FMA           0x100u /* with D1: v_muladd fused (an AVX2/FMA3-baseline build) */
 #define ORC_OCV_D1_W4            0x200u /* with D1: the OpenCV 3.x SSE2 form (4 elements per step for A, sequential 4-lane reduce) */
 #define ORC_OCV_D1_SCALAR        0x400u /* with D1: no SIMD at all (plain float accumulation in element order) */

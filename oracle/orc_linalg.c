@@ -8,12 +8,54 @@
 #include <math.h>
 #include <string.h>
 
+/* sum of 12 terms in the order the EPnP kernel's lanes produce it (experiment switch ORC_ALT_J12_*: 0 sequential) */
+static double sum12(const double* t, int mode) {
+    int k; double s = 0;
+    if (mode == 1) {            /* halves: (t0+..+t5) + (t6+..+t11), each from zero */
+        double lo = 0, hi = 0;
+        for (k = 0; k < 6; k++) lo += t[k];
+        for (k = 6; k < 12; k++) hi += t[k];
+        return lo + hi;
+    }
+    if (mode == 2) {            /* quarters: ((t0+t1+t2) + (t3+t4+t5)) + ((t6+t7+t8) + (t9+t10+t11)) */
+        double q[4];
+        for (k = 0; k < 4; k++) q[k] = (t[3 * k] + t[3 * k + 1]) + t[3 * k + 2];
+        return (q[0] + q[1]) + (q[2] + q[3]);
+    }
+    for (k = 0; k < 12; k++) s += t[k];
+    return s;
+}
+
 /* One Hestenes rotation of rows i < j of At (and of Vt).  Returns 1 if the pair was rotated. */
 static int rotate_pair(double* At, int m, int n, double* W, double* Vt, int i, int j) {
     const double eps = DBL_EPSILON * 10;
     double* Ai = At + i * m; double* Aj = At + j * m;
     double a = W[i], p = 0, b = W[j], c, s;
     int k;
+    const unsigned ocv = orc_get_opencv_mode();
+    const int mode12 = (m == 12 && n == 12) ? ((ocv & ORC_ALT_J12_HALVES) ? 1 : (ocv & ORC_ALT_J12_QUARTERS) ? 2 : 0) : 0;
+    if (mode12) {
+        double t[12], u[12], v[12];
+        for (k = 0; k < 12; k++) t[k] = Ai[k] * Aj[k];
+        p = sum12(t, mode12);
+        if (fabs(p) <= eps * sqrt(a * b)) return 0;
+        p *= 2;
+        {
+            double beta = a - b, gamma = (ocv & ORC_OCV_HYPOT) ? hypot(p, beta) : sqrt(p * p + beta * beta);
+            if (beta < 0) { double delta = (gamma - beta) * 0.5; s = sqrt(delta / gamma); c = p / (gamma * s * 2); }
+            else { c = sqrt((gamma + beta) / (gamma * 2)); s = p / (gamma * c * 2); }
+        }
+        for (k = 0; k < 12; k++) {
+            double t0 = c * Ai[k] + s * Aj[k], t1 = -s * Ai[k] + c * Aj[k];
+            Ai[k] = t0; Aj[k] = t1; u[k] = t0 * t0; v[k] = t1 * t1;
+        }
+        W[i] = sum12(u, mode12); W[j] = sum12(v, mode12);
+        if (Vt) {
+            double* Vi = Vt + i * n; double* Vj = Vt + j * n;
+            for (k = 0; k < n; k++) { double t0 = c * Vi[k] + s * Vj[k], t1 = -s * Vi[k] + c * Vj[k]; Vi[k] = t0; Vj[k] = t1; }
+        }
+        return 1;
+    }
     for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
     if (fabs(p) <= eps * sqrt(a * b)) return 0;
     p *= 2;

@@ -25,6 +25,11 @@ void orc_triangulate(const float Pl[12], const float Pr[12], int n, const float*
             A[2 * 4 + k] = xr * (double)Pr[8 + k] - (double)Pr[0 + k];
             A[3 * 4 + k] = yr * (double)Pr[8 + k] - (double)Pr[4 + k];
         }
+        if (orc_get_opencv_mode() & ORC_ALT_TRI_RR) {
+            int r, cc;
+            for (r = 0; r < 4; r++) for (cc = 0; cc < 4; cc++) Ut[r * 4 + cc] = A[cc * 4 + r];
+            orc_jacobi_svd_ord(Ut, 4, 4, W, Vt, 4, 1);
+        } else
         orc_svd(A, 4, 4, W, Ut, Vt);
         float X = (float)Vt[12], Y = (float)Vt[13], Z = (float)Vt[14], Wh = (float)Vt[15];   /* 4xN output is CV_32F */
         if (homog) { homog[4 * i] = X; homog[4 * i + 1] = Y; homog[4 * i + 2] = Z; homog[4 * i + 3] = Wh; }

@@ -61,6 +61,10 @@ class SvoFrameStats(C.Structure):
 
 
 lib.svo_last_error.restype = C.c_char_p
+lib.svo_alloc_pinned.restype = C.c_void_p
+lib.svo_alloc_pinned.argtypes = [C.c_size_t]
+lib.svo_free_pinned.restype = None
+lib.svo_free_pinned.argtypes = [C.c_void_p]
 lib.svo_get_stream.restype = C.c_void_p
 lib.svo_stage_cache_clear.restype = None
 lib.svo_stage_cache_clear.argtypes = []
@@ -69,7 +73,7 @@ lib.svo_get_stream.argtypes = [C.c_void_p]
 # every symbol include/svo.h declares (tests/test_abi.py checks the list against the header)
 EXPORTS = [
     "svo_last_error", "svo_device_count", "svo_config_default", "svo_create", "svo_destroy", "svo_set_projection",
-    "svo_process_batch", "svo_process", "svo_circular_matching", "svo_submit_batch", "svo_collect", "svo_get_features", "svo_get_last_tracks",
+    "svo_process_batch", "svo_process", "svo_alloc_pinned", "svo_free_pinned", "svo_circular_matching", "svo_submit_batch", "svo_collect", "svo_get_features", "svo_get_last_tracks",
     "svo_get_lk_registers_left", "svo_get_last_timing", "svo_set_stage_timing", "svo_get_stage_timing", "svo_get_stream", "svo_fast_detect", "svo_fast_score_map", "svo_bucket_filter",
     "svo_append_features_from_image", "svo_build_pyramid", "svo_lk_track", "svo_circular_match",
     "svo_find_close_points", "svo_stage_cache_clear", "svo_stage_cache_clear_all", "svo_triangulate", "svo_camera_to_world", "svo_inverse_transform",

@@ -231,6 +231,25 @@ class Bucket:
         return self.features.size()
 
 
+class PinnedImage:
+    """An (H, W) or (H, W, 3) uint8 numpy array living in page-locked host memory (svo_alloc_pinned): frames kept in such
+    buffers are read by the DMA engines in place instead of being copied to a staging buffer first (include/svo.h)."""
+
+    def __init__(self, shape):
+        self._n = int(np.prod(shape))
+        self._p = lib.svo_alloc_pinned(self._n)
+        if not self._p:
+            raise MemoryError("svo_alloc_pinned(%d)" % self._n)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * self._n).from_address(self._p)).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self._p:
+                lib.svo_free_pinned(self._p); self._p = None
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------------------- VisualOdometry
 class BatchVisualOdometry:
     """n_seq independent VisualOdometry instances advancing in lock-step on one GPU."""

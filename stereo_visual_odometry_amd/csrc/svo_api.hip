@@ -448,7 +448,23 @@ extern "C" int svo_process(svo_context* c, const uint8_t* left, const uint8_t* r
     return rc != SVO_OK ? rc : ok;
 }
 
+// Is p page-locked host memory the DMA engines can read in place (hipHostMalloc / hipHostRegister / svo_alloc_pinned)?
+static bool host_pointer_is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // older runtimes: an error for pageable memory
+    return a.type == hipMemoryTypeHost;
+}
+
+extern "C" void* svo_alloc_pinned(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void svo_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+
 // Host images -> pinned staging -> device staging (one contiguous H2D copy); fills lp / rp with the device addresses.
+// Images that already live in page-locked memory with packed rows skip the staging copy: the DMA reads them in place (the call
+// is synchronous, the caller's buffer outlives it) — 40 us of host memcpy less per KITTI-sized pair on the single-stream path.
 static int stage_host_images(svo_context* c, const uint8_t* const* left, const uint8_t* const* right, int stride,
                              std::vector<const uint8_t*>& lp, std::vector<const uint8_t*>& rp) {
     const int B = c->d.B, W = c->d.geom.W, H = c->d.geom.H;
@@ -461,14 +477,20 @@ static int stage_host_images(svo_context* c, const uint8_t* const* left, const u
     lp.resize(B); rp.resize(B);
     for (int cam = 0; cam < 2; cam++) {
         const uint8_t* const* src = cam ? right : left;
+        bool all_direct = (size_t)stride == rowb;
+        for (int i = 0; i < B && all_direct; i++) { if (!src[i]) return fail_arg("null image pointer"); all_direct = host_pointer_is_pinned(src[i]); }
         for (int i = 0; i < B; i++) {
             if (!src[i]) return fail_arg("null image pointer");
+            (cam ? rp : lp)[i] = c->staging + img * (cam * B + i);
+            if (all_direct) {
+                HIPCHK(hipMemcpyAsync(c->staging + img * (cam * B + i), src[i], img, hipMemcpyHostToDevice, c->stream));
+                continue;
+            }
             uint8_t* h = c->h_staging + img * (cam * B + i);
             if ((size_t)stride == rowb) memcpy(h, src[i], img);
             else for (int y = 0; y < H; y++) memcpy(h + (size_t)y * rowb, src[i] + (size_t)y * stride, rowb);
-            (cam ? rp : lp)[i] = c->staging + img * (cam * B + i);
         }
-        HIPCHK(hipMemcpyAsync(c->staging + img * B * cam, c->h_staging + img * B * cam, img * B, hipMemcpyHostToDevice, c->stream));
+        if (!all_direct) HIPCHK(hipMemcpyAsync(c->staging + img * B * cam, c->h_staging + img * B * cam, img * B, hipMemcpyHostToDevice, c->stream));
     }
     return SVO_OK;
 }

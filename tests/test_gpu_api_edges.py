@@ -185,6 +185,31 @@ def test_graph_replay_equals_the_launch_list(api, monkeypatch):
     assert sum(r[0] for r in outs["1"]) >= 9
 
 
+def test_frames_in_page_locked_memory_take_the_copy_free_path_and_give_the_same_results(api):
+    """svo_alloc_pinned: images in page-locked memory with packed rows are DMA'd in place; pageable ones, padded rows, and a batch
+    that mixes both go through the staging copy — all must give identical poses and counters."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=320, height=160, cx=160.0, cy=80.0)
+    seq = syn.StereoSequence(cal=cal, n_frames=5, seed=3, step=0.3)
+    P = syn.projection_matrices(cal)
+    over = dict(max_translation_norm=2.0)
+    ref = api.BatchVisualOdometry(320, 160, 2, api.default_config(**over)); ref.initalize_projection_matricies(*P)
+    pin = api.BatchVisualOdometry(320, 160, 2, api.default_config(**over)); pin.initalize_projection_matricies(*P)
+    mix = api.BatchVisualOdometry(320, 160, 2, api.default_config(**over)); mix.initalize_projection_matricies(*P)
+    bufs = [api.PinnedImage((160, 320)) for _ in range(4)]
+    for k in range(4):
+        L = [seq.left[k], seq.left[k + 1]]; R = [seq.right[k], seq.right[k + 1]]
+        ok0, T0 = ref.stereo_callback_batch(L, R)
+        for b, im in zip(bufs, L + R):
+            b.array[:] = im
+        ok1, T1 = pin.stereo_callback_batch([bufs[0].array, bufs[1].array], [bufs[2].array, bufs[3].array])
+        ok2, T2 = mix.stereo_callback_batch([bufs[0].array, L[1]], [R[0], bufs[3].array])
+        for ok, T, vo in ((ok1, T1, pin), (ok2, T2, mix)):
+            assert np.array_equal(ok, ok0) and np.array_equal(T, T0), k
+            assert [s.as_dict() for s in vo.stats] == [s.as_dict() for s in ref.stats], k
+    assert ok0.all()
+
+
 def test_lk_kernel_leaves_room_for_the_other_contexts_kernels(api):
     """The default LK build at the metric's 21x21 window must stay at <= 104 registers (four waves per SIMD, 96 registers left):
     only then do two many-sequence contexts overlap one's f64 kernels with the other's LK kernel — a change to the
