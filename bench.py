@@ -127,6 +127,8 @@ def main():
                     "replay) through a one-sequence context and through the CPU oracle, outside the timed region (0 = only the timed steps of slot 0)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg5"],
                     help="BASELINE.json configs[1] (the metric's configuration, default) / configs[2] / configs[4]; the others are extra measurements")
+    ap.add_argument("--float-sums", type=int, default=0, help="1 = svo_config.lk_float_sums (LK sums in float in OpenCV's SIMD128 lane order: the mode that "
+                    "reproduces the reference's recording digit for digit; several times slower in LK).  An extra measurement, not the bench line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
@@ -193,6 +195,8 @@ def main():
         args.movers = 0.3 if args.workload == "cfg2" else 0.0
     W, H = cal["width"], cal["height"]
     over = dict(win_w=win, win_h=win, max_translation_norm=2.0, **cfg_over)
+    if args.float_sums:
+        over["lk_float_sums"] = 1
     B, F = args.seqs, args.frames
     seed0 = scene.pop("seed")
     pool = [syn.StereoSequence(cal=cal, n_frames=F, seed=seed0 + 97 * rank + g, movers=args.movers, **scene)
@@ -419,7 +423,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int64/f32 (LK), f64 (PnP)",
             "data": "synthetic",
-            "config": {"workload": workload_name + "; max_translation_norm 2.0 (reference 0.1: its gate is tuned for a 3 cm/frame rover, "
+            "config": {"workload": workload_name + ("; lk_float_sums = 1 (OpenCV-order float sums)" if args.float_sums else "") + "; max_translation_norm 2.0 (reference 0.1: its gate is tuned for a 3 cm/frame rover, "
                                    "the scene moves 0.5 m/frame); %.0f %% of the pixels on an independently moving layer" % (100 * args.movers),
                        "sequences_per_gpu": B, "contexts_per_gpu": C, "frames_in_flight": depth, "mean_features_into_lk": N,
                        "mean_tracks_after_bounds": float(np.mean(n_bounds)), "mean_inliers": float(np.mean(n_inl)),

@@ -276,6 +276,9 @@ __device__ __forceinline__ void load_pairs(const uint8_t* __restrict__ p, unsign
 // Mapping: the owner lanes write their per-element integers to LDS ([row][e]); five CHAIN lanes per sum (four SIMD lanes + the
 // tail) walk their elements in OpenCV's order with one dependent float add each — a serial chain by construction (105 adds for
 // the tail at W = 21), which is why this mode costs several times the default's Newton step and is opt-in.
+#ifndef FS_UNROLL
+#define FS_UNROLL 7
+#endif
 template <int W, int CN> struct LkFs {
     static constexpr int E = W * CN, NSIMD = (E / 8) * 8;
     static constexpr int CNT_S = NSIMD / 4, CNT_T = E - NSIMD, MAXC = CNT_S > CNT_T ? CNT_S : CNT_T;     // A: elements per row of a SIMD / the tail chain
@@ -292,17 +295,25 @@ __device__ __forceinline__ void fs_sum_A(const int* __restrict__ lds, float (&As
     const int lane = threadIdx.x & 63, c = lane & 7, which = lane >> 3;
     const int e0 = c < 4 ? c : F::NSIMD, stride = c < 4 ? 4 : 1;
     const int cnt = (which < 3) ? (c < 4 ? F::CNT_S : (c == 4 ? F::CNT_T : 0)) : 0;
+    // Branch-free: every lane reads MAXC elements per row (indices beyond its count re-read its first element, always a valid
+    // address) and a select keeps the running sum where the element does not count — per-element exec-mask branches made every
+    // LDS read wait for the one before it (measured: the mode's LK time 13.8 -> see DESIGN.md).
+    int off[F::MAXC]; bool on[F::MAXC];
+#pragma unroll
+    for (int i = 0; i < F::MAXC; i++) { on[i] = i < cnt; off[i] = e0 + (on[i] ? i * stride : 0); }
     float acc = 0.f;
+#pragma unroll FS_UNROLL
     for (int y = 0; y < W; y++) {
-        const int* rp = lds + y * F::E + e0;
+        const int* rp = lds + y * F::E;
+        int v[F::MAXC];
+#pragma unroll
+        for (int i = 0; i < F::MAXC; i++) v[i] = rp[off[i]];
 #pragma unroll
         for (int i = 0; i < F::MAXC; i++) {
-            if (i < cnt) {
-                const int v = rp[i * stride];
-                const float fx = (float)(short)(v & 0xFFFF), fy = (float)(v >> 16);
-                const float a = which == 2 ? fy : fx, b = which == 0 ? fx : fy;
-                acc = a * b + acc;                                   // two roundings (the file is built with -ffp-contract=off)
-            }
+            const float fx = (float)(short)(v[i] & 0xFFFF), fy = (float)(v[i] >> 16);
+            const float a = which == 2 ? fy : fx, b = which == 0 ? fx : fy;
+            const float nacc = a * b + acc;                              // two roundings (the file is built with -ffp-contract=off)
+            acc = on[i] ? nacc : acc;
         }
     }
 #pragma unroll
@@ -319,17 +330,22 @@ __device__ __forceinline__ void fs_sum_b(const int* __restrict__ lds, float& b1,
     const int lane = threadIdx.x & 63, c = lane & 7, xy = lane >> 3;
     const int cnt = (xy < 2) ? (c < 4 ? F::NG : (c == 4 ? F::CNT_T : 0)) : 0;
     const int e0 = c < 4 ? c : F::NSIMD, stride = c < 4 ? 8 : 1;
-    const int* P = lds + (xy & 1) * (W * F::E) + e0;
+    const int* P = lds + (xy & 1) * (W * F::E);
+    const bool paired = c < 4;                                           // v_dotprod: element k with element k + 4, exact
+    int off[F::MAXB], off2[F::MAXB]; bool on[F::MAXB];
+#pragma unroll
+    for (int i = 0; i < F::MAXB; i++) { on[i] = i < cnt; off[i] = e0 + (on[i] ? i * stride : 0); off2[i] = off[i] + ((paired && on[i]) ? 4 : 0); }
     float acc = 0.f;
+#pragma unroll FS_UNROLL
     for (int y = 0; y < W; y++) {
         const int* rp = P + y * F::E;
+        int v[F::MAXB], v2[F::MAXB];
+#pragma unroll
+        for (int i = 0; i < F::MAXB; i++) { v[i] = rp[off[i]]; v2[i] = rp[off2[i]]; }
 #pragma unroll
         for (int i = 0; i < F::MAXB; i++) {
-            if (i < cnt) {
-                int v = rp[i * stride];
-                if (c < 4) v += rp[i * stride + 4];                  // v_dotprod: element k with element k + 4, exact
-                acc += (float)v;
-            }
+            const float nacc = acc + (float)(v[i] + (paired ? v2[i] : 0));
+            acc = on[i] ? nacc : acc;
         }
     }
     const float x0 = lane_f(acc, 0), x1 = lane_f(acc, 1), x2 = lane_f(acc, 2), x3 = lane_f(acc, 3), xt = lane_f(acc, 4);

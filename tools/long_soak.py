@@ -1,5 +1,5 @@
 """One-off long soak (not part of the test suite): N full-resolution cfg2 frames through the HIP path and the CPU oracle side by
-side; every frame's flags, counters and feature set must match bit for bit.  usage: python tools/long_soak.py [frames] [step_m] [movers] [window]
+side; every frame's flags, counters and feature set must match bit for bit.  usage: python tools/long_soak.py [frames] [step_m] [movers] [window] [float_sums]
 Round-1 results on an MI355X box: 200 frames, step 0.08 m: 0 mismatching frames, 199 poses, max |dt| 1.1e-9 m, ATE 5.2 cm over
 15.9 m vs ground truth, 5.5e-10 m vs the oracle; step 0.5 m (the camera flies out of the rendered scene after ~40 frames, so most
 frames take the failure paths): 0 mismatching frames as well.
@@ -13,7 +13,8 @@ orc.set_threads(16)
 cal=syn.KITTI00; NF=int(sys.argv[1]) if len(sys.argv)>1 else 200
 t=time.time(); seq=syn.StereoSequence(cal=cal,n_frames=NF,seed=0x5EED0042,step=float(sys.argv[2]) if len(sys.argv)>2 else 0.5,cell_px=17.6,yaw_amp_deg=0.5,movers=float(sys.argv[3]) if len(sys.argv)>3 else 0.0); print('rendered',NF,'frames in',round(time.time()-t,1),'s',flush=True)
 WIN=int(sys.argv[4]) if len(sys.argv)>4 else 21
-over=dict(win_w=WIN,win_h=WIN,max_level=3,ransac_iterations=100,max_translation_norm=2.0)
+FS=int(sys.argv[5]) if len(sys.argv)>5 else 0          # 1 = lk_float_sums on both sides
+over=dict(win_w=WIN,win_h=WIN,max_level=3,ransac_iterations=100,max_translation_norm=2.0,lk_float_sums=FS)
 Pl,Pr=syn.projection_matrices(cal)
 o=orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl,Pr)
 g=api.VisualOdometry(cfg=api.default_config(**over)); g.initalize_projection_matricies(Pl,Pr)
