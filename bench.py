@@ -321,8 +321,10 @@ def main():
             try:
                 j = json.load(open(pmcs[-1]))
                 traffic = j["hbm_bytes_per_launch"] * Bc / float(j.get("sequences_per_launch", 32))
-                traffic_src = "committed rocprofv3 --pmc passes, profiles/%s, rescaled from %d to %d sequences per launch" % (
-                    os.path.basename(pmcs[-1]), int(j.get("sequences_per_launch", 32)), Bc)
+                ps = int(j.get("sequences_per_launch", 32))
+                traffic_src = "committed rocprofv3 --pmc passes of this same command (FETCH_SIZE, WRITE_SIZE in separate passes), profiles/%s, %s" % (
+                    os.path.basename(pmcs[-1]), "taken at this launch size (%d sequences per launch)" % ps if ps == Bc else
+                    "rescaled from %d to %d sequences per launch" % (ps, Bc))
             except Exception:
                 traffic = None
         # secondary (SURVEY.md 8d asks for the VALU view too, the kernel being instruction-bound): share of the GPU's VALU

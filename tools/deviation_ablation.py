@@ -29,6 +29,7 @@ REF_RUN1 = "/root/reference/run1"
 
 D1, D2, D3R, D4, D5, HYPOT = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20          # D3R: the FORMER deviation D3 (right singular vectors) back in force
 D1_FMA, D1_W4, D1_SCALAR = 0x100, 0x200, 0x400
+J12_HALVES, J12_QUARTERS, TRI_RR = 0x1000, 0x2000, 0x4000                  # experiments: candidate latency cuts of the HIP kernels
 
 SETTINGS = [
     ("the oracle as shipped (D1, D2, D4, D5 in force)", 0),
@@ -46,6 +47,10 @@ SETTINGS = [
     ("D1+D5 reverted", D1 | D5),
     ("D1 reverted + libm hypot in every Jacobi rotation", D1 | HYPOT),
     ("D1+D2+D4+D5 reverted + hypot", D1 | D2 | D4 | D5 | HYPOT),
+    ("candidate cut: D1 reverted + 12-term sums of EPnP's Jacobi as two halves", D1 | J12_HALVES),
+    ("candidate cut: D1 reverted + 12-term sums of EPnP's Jacobi as four quarters", D1 | J12_QUARTERS),
+    ("candidate cut: D1 reverted + round-robin 4x4 sweep in the triangulation", D1 | TRI_RR),
+    ("candidate cut: quarters, D1 in force (the default mode)", J12_QUARTERS),
 ]
 
 
