@@ -492,12 +492,12 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const bool on = (EXT == W) || (xs + j < W);
-                const int iacc = dot2(Ip[1][j], w1, dot2(Ip[0][j], w0, 1 << (LK_WBITS - 6)));          // I = iacc >> (WBITS-5)
+                const int iacc = dot2(Ip[1][j], w1, dot2_keep(Ip[0][j], w0, 1 << (LK_WBITS - 6)));          // I = iacc >> (WBITS-5); the rounding term rides in as the (scalar) addend of the three-address form: no v_mov per pixel
                 Kr[kk][j] = (1 << (LK_WBITS - 6)) - (iacc & ~((1 << (LK_WBITS - 5)) - 1));
                 // the derivative pairs carry 4 x the Scharr value (coefficients 12 / 40 above, still inside 16 bits), so the
                 // 14-bit descale of the bilinear sum becomes "take the upper half": (4 S + 2^15) >> 16 == (S + 2^13) >> 14
-                const int ixacc = dot2(DXp[1][j], wd1, dot2(DXp[0][j], wd0, 1 << (LK_WBITS + 1)));
-                const int iyacc = dot2(DYp[1][j], wd1, dot2(DYp[0][j], wd0, 1 << (LK_WBITS + 1)));
+                const int ixacc = dot2(DXp[1][j], wd1, dot2_keep(DXp[0][j], wd0, 1 << (LK_WBITS + 1)));
+                const int iyacc = dot2(DYp[1][j], wd1, dot2_keep(DYp[0][j], wd0, 1 << (LK_WBITS + 1)));
                 ixv[j] = on ? ixacc : 0; iyv[j] = on ? iyacc : 0;
                 if constexpr (FS) {
                     if (sg.on[k] && on) fs_lds[row * FE + (xs + j) * CN + kk / SPL] = (int)pack_hi16(ixacc, iyacc);
