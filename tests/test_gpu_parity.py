@@ -896,6 +896,46 @@ class _Frames:
         self.cal, self.left, self.right = seq.cal, left, right
 
 
+def test_full_size_properties_determinism_and_slot_independence(api):
+    """Size-independent properties at BASELINE cfg2's full size, where the oracle is too slow to sit beside every frame:
+      * determinism — the same frames through two fresh contexts give identical bits (poses, counters), run to run;
+      * slot independence — a sequence's results do not depend on which slot of a batch it occupies or on what its neighbours
+        are (the permuted batch returns the permuted results), nor on the batch size (1 vs 5);
+      * a context that sees frame k twice in a row reports (numerically) no motion the second time."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = syn.KITTI00
+    W, H = cal["width"], cal["height"]
+    P = syn.projection_matrices(cal)
+    seqs = [syn.StereoSequence(cal=cal, n_frames=4, seed=0x5EED0100 + s, step=0.5, cell_px=17.6, movers=0.3 if s % 2 else 0.0) for s in range(3)]
+    over = dict(win_w=21, win_h=21, max_level=3, max_translation_norm=2.0)
+
+    def run(order, n_frames=4):
+        vo = api.BatchVisualOdometry(W, H, len(order), api.default_config(**over)); vo.initalize_projection_matricies(*P)
+        out = []
+        for k in range(n_frames):
+            ok, T = vo.stereo_callback_batch([seqs[s].left[k] for s in order], [seqs[s].right[k] for s in order])
+            out.append((ok.copy(), T.copy(), [st.as_dict() for st in vo.stats]))
+        vo.close()
+        return out
+
+    a = run([0, 1, 2]); b = run([0, 1, 2])
+    for (ok1, T1, s1), (ok2, T2, s2) in zip(a, b):
+        assert np.array_equal(ok1, ok2) and np.array_equal(T1, T2) and s1 == s2                     # bit-identical, run to run
+    perm = [2, 0, 1, 2, 1]
+    c = run(perm)
+    for k in range(4):
+        for slot, s in enumerate(perm):
+            assert c[k][0][slot] == a[k][0][s] and np.array_equal(c[k][1][slot], a[k][1][s]) and c[k][2][slot] == a[k][2][s], (k, slot)
+    single = run([1])
+    for k in range(4):
+        assert np.array_equal(single[k][1][0], a[k][1][1]) and single[k][2][0] == a[k][2][1]
+    assert all(x[0].all() for x in a[1:]) and a[1][2][0]["n_into_lk"] > 1500
+    vo = api.BatchVisualOdometry(W, H, 1, api.default_config(**over)); vo.initalize_projection_matricies(*P)
+    for k in (0, 1, 1):
+        ok, T = vo.stereo_callback_batch([seqs[0].left[k]], [seqs[0].right[k]])
+    assert ok[0] and np.abs(T[0] - np.eye(4)).max() < 1e-3
+
+
 FUZZ_CASES = int(os.environ.get("SVO_FUZZ_CASES", "16"))          # the suite runs 16; SVO_FUZZ_CASES=400 for a one-off sweep
 
 

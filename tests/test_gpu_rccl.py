@@ -112,3 +112,39 @@ def test_c_entry_of_the_pose_gather_on_a_one_device_communicator():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and "GATHER OK 1" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_cfg4_from_a_cpp_host_matches_the_python_api(tmp_path):
+    """BASELINE configs[3] without Python in the data path: tools/svo_multi_gpu.cpp shards S sequences over the devices (one host
+    thread each, the reference's driver loop per GPU), gathers the pose streams through libsvo_rccl.so and writes one
+    result_seqNN.csv per sequence.  One device here; the trajectories must equal those of the Python API on the same frames."""
+    import subprocess
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from stereo_visual_odometry_amd import api, evaluate, synthetic as syn
+    cal = dict(syn.KITTI00, width=320, height=160, cx=160.0, cy=80.0)
+    S, F = 3, 5
+    seqs = [syn.StereoSequence(cal=cal, n_frames=F, seed=0x5EED0040 + s, step=0.3) for s in range(S)]
+    path = tmp_path / "frames.bin"
+    with open(path, "wb") as f:
+        f.write(np.array([S, F, 160, 320], np.int32).tobytes())
+        f.write(np.array([cal["fx"], cal["cx"], cal["cy"], cal["bf"]], np.float32).tobytes())
+        for q in seqs:
+            for l, r in zip(q.left, q.right):
+                f.write(l.tobytes()); f.write(r.tobytes())
+    exe = os.path.join(ROOT, "tools", "svo_multi_gpu")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "svo_multi_gpu.cpp"), "-o", exe, "-L" + os.path.join(ROOT, "stereo_visual_odometry_amd"),
+                           "-lsvo_hip", "-lsvo_rccl", "-Wl,-rpath," + os.path.join(ROOT, "stereo_visual_odometry_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, str(path), "1", str(tmp_path), "10", "2.0"], capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "MULTI OK 3 sequences 5 frames 1 devices" in out.stdout, out.stdout + out.stderr
+    Pl, Pr = syn.projection_matrices(cal)
+    for s, q in enumerate(seqs):
+        vo = api.VisualOdometry(cfg=api.default_config(max_translation_norm=2.0)); vo.initalize_projection_matricies(Pl, Pr)
+        pose, track = np.eye(4), []
+        for k in range(F):
+            ok, T = vo.stereo_callback(q.left[k], q.right[k])
+            pose = pose @ T; track.append(pose[:3, 3].copy())
+        rows = evaluate.read_result_csv(tmp_path / ("result_seq%02d.csv" % s))
+        assert rows.shape[0] == F and np.abs(rows[:, :3] - np.array(track)).max() < 1e-8, s
