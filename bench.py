@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--seqs", type=int, default=256, help="independent stereo sequences batched per GPU")
     ap.add_argument("--depth", type=int, default=4, help="frames kept in flight per context (<= 8)")
     ap.add_argument("--contexts", type=int, default=2, help="sequence groups per GPU, each on its own HIP stream (their kernels overlap)")
-    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic sequences rendered per rank (own seed each)")
+    ap.add_argument("--pool", type=int, default=16, help="distinct synthetic sequences rendered per rank (own seed each)")
     ap.add_argument("--movers", type=float, default=None, help="fraction of the pixels covered by an independently moving foreground layer "
                     "(RANSAC-PnP outliers; 0 = static scene, the best case for PnP).  Default: 0.3 for cfg2 (the metric's workload), 0 for the others")
     ap.add_argument("--frames", type=int, default=10, help="frames rendered per pool sequence (ping-pong replay)")
@@ -380,7 +380,7 @@ def main():
             cpu = {"value": allc, "unit": "frame-pairs/s", "cores": cores, "kind": "port", "opencv": opencv_probe(pool[0], cal, over, ping_pong, args.cpu_frames),
                    "sample": "%d frame pairs of pool sequence 0 of the same workload through oracle/ — this repo's plain-C RESTATEMENT of the "
                              "reference's pipeline and of the OpenCV 4.5 calls it makes, NOT OpenCV itself (absent from the image) — built %s, "
-                             "OpenMP over the points of each LK pass and over image rows, %d threads; single thread: %.2f frame-pairs/s"
+                             "OpenMP over the points of each LK pass and over image rows (the LK inner loops are auto-vectorised by gcc), %d threads; single thread: %.2f frame-pairs/s"
                              % (args.cpu_frames, orc_build, cores, single)}
         # ATE (the second half of BASELINE.json's metric), outside the timed region: slot 0's pose stream over the timed steps,
         # integrated as frame_pose = frame_pose * T (main.cpp:396), against the renderer's ground truth for the same frame
