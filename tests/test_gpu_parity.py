@@ -431,6 +431,20 @@ def test_circular_match_parity_stereo_scene(api, win):
     for g, o in zip(got[:4], want[:4]):
         assert np.array_equal(bits(g), bits(o))
     assert 0.3 * len(fxy) < want[4].sum() < len(fxy)       # both outcomes occur
+    # the same stage call in float-sums mode (oracle: D1 reverted): the member / stage form runs ALL four passes of every point
+    # (no early-out: the caller gets every pass's raw points), also for points that die in an early pass
+    cfg.lk_float_sums = 1
+    pts = np.concatenate([fxy, np.array([[2.0, 3.0], [478.5, 1.5], [-4.0, 50.0]], np.float32)])      # some that leave the image
+    got = api.circularMatching(cfg, seq.left[0], seq.right[0], seq.left[1], seq.right[1], pts)
+    prev = orc.lib().orc_set_opencv_mode(1)
+    try:
+        want_fs = orc.circular_match(P[0], P[1], P[2], P[3], pts, ocfg)
+    finally:
+        orc.lib().orc_set_opencv_mode(prev)
+    assert np.array_equal(got[4], want_fs[4])
+    for g, o in zip(got[:4], want_fs[:4]):
+        assert np.array_equal(bits(g), bits(o))
+    assert not all(np.array_equal(bits(a), bits(b)) for a, b in zip(want_fs[:4], [w[:len(pts)] for w in orc.circular_match(P[0], P[1], P[2], P[3], pts, ocfg)[:4]]))
 
 
 # ---------------------------------------------------------------- triangulation / PnP
