@@ -304,10 +304,14 @@ static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_e
     const bool shares_device = shares < 0 ? lk_gated(c) : shares != 0;   // read once per frame: both uses below see the same answer
     d.co_resident = (shares_device || force_lean) ? 1 : 0;             // picks the 96-register builds of the f64 kernels (svo_kernels_pnp.hip)
     const uint8_t** dp = d.img_ptrs + (size_t)slot * 2 * B;         // the slot's pointer table: pinned host memory the kernel reads in place
-    launch_ingest_pyramid(d, dp, stride, s, true);                    // + the per-frame reset
-    if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
-    launch_detect(d, 0, -1, s);
-    launch_detect(d, 1, -1, s);
+    if (launch_front_fused(d, dp, stride, s)) {                        // lone stream: ingest + pyramid beside detection, two launches
+        if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));   // stage timers: ms[0] = the fused front, ms[1] ~ 0
+    } else {
+        launch_ingest_pyramid(d, dp, stride, s, true);                // + the per-frame reset
+        if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
+        launch_detect(d, 0, -1, s);
+        launch_detect(d, 1, -1, s);
+    }
     const bool gated = !c->capturing && shares_device;
     if (gated) {
         LkGate& g = g_lk_gate[c->device];

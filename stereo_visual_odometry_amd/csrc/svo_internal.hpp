@@ -2,6 +2,7 @@
 // Product code (gfx950 only).  Never includes anything from oracle/.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "../../include/svo.h"
 
@@ -114,6 +115,9 @@ void launch_pnp(const DevBuffers& d, hipStream_t s);                   // expect
 void launch_pnp_subsets(const DevBuffers& d, hipStream_t s);
 void launch_pnp_p3p(const DevBuffers& d, hipStream_t s);                // exactly four points: one P3P, no RANSAC (stage API only)
 void launch_inverse_transform(const double* R, const double* t, double* T, hipStream_t s);   // device pointers
+// the front of a lone stream's frame as two fused launches (ingest + level 1 || FAST pass 0; levels 2-3 || emit), then the second
+// detection pass; false = not applicable to this context, nothing was launched
+bool launch_front_fused(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride, hipStream_t s);
 void launch_frame_end(const DevBuffers& d, int ring_slot, hipStream_t s);
 
 // stage helpers

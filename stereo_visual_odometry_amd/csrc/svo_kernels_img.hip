@@ -168,18 +168,19 @@ __global__ __launch_bounds__(256) void k_pyrdown(DevBuffers d, int level) {
 // ---- fewer launches for the front of a frame (a lone stream is launch-bound there: a 5 us kernel every 4.5 us of host time) ----
 // k_ingest_pyr1: ingest and the first pyrDown in one launch (single-channel contexts).  A block stages the 67 x 19 source tile of
 // its 32 x 8 level-1 outputs straight from the caller's image, writes the 64 x 16 level-0 pixels it owns and the level-1 tile.
-__global__ __launch_bounds__(256) void k_ingest_pyr1(DevBuffers d, const uint8_t* const* srcs, int stride, int begin_frame) {
-    const int seq = blockIdx.z >> 1, cam = blockIdx.z & 1;
+// (bodies take their block coordinates as arguments so that k_front_a / k_front_b below can run two of them in one launch)
+static __device__ __forceinline__ void ingest_pyr1_body(const DevBuffers& d, const uint8_t* const* srcs, int stride, int begin_frame, int bx, int by, int bz) {
+    const int seq = bz >> 1, cam = bz & 1;
     const LevelInfo ls = d.geom.lv[0], ld = d.geom.lv[1];
     const uint8_t* src = srcs[cam * d.B + seq];
     const int slot = begin_frame ? free_slot(d.st[seq]) : d.st[seq].slot_t1;
-    if (begin_frame && blockIdx.x == 0 && blockIdx.y == 0 && cam == 0 && threadIdx.x == 0) frame_begin(d.st[seq]);
+    if (begin_frame && bx == 0 && by == 0 && cam == 0 && threadIdx.x == 0) frame_begin(d.st[seq]);
     uint8_t* base = d.pyr + pyr_index(d, seq, slot, cam);
     uint8_t* l0 = base + ls.off; uint8_t* dst = base + ld.off;
     constexpr int SW = 2 * PD_TW + 3, SH = 2 * PD_TH + 3;        // 67 x 19 source tile
     __shared__ __attribute__((aligned(4))) uint8_t tile[SH][SW + 1];
     __shared__ unsigned short hrow[SH][PD_TW];
-    const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
+    const int ox = bx * PD_TW, oy = by * PD_TH;
     const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
     struct __attribute__((packed, aligned(1))) UD { unsigned v; };
     if (sx0 >= 0 && sy0 >= 0 && sx0 + SW + 1 <= ls.w && sy0 + SH <= ls.h) {
@@ -222,6 +223,9 @@ __global__ __launch_bounds__(256) void k_ingest_pyr1(DevBuffers d, const uint8_t
         }
     }
 }
+__global__ __launch_bounds__(256) void k_ingest_pyr1(DevBuffers d, const uint8_t* const* srcs, int stride, int begin_frame) {
+    ingest_pyr1_body(d, srcs, stride, begin_frame, blockIdx.x, blockIdx.y, blockIdx.z);
+}
 
 // k_pyrdown2: levels l+1 AND l+2 from level l in one launch.  A block owns a 16 x 8 tile of level l+2, i.e. 32 x 16 of level l+1;
 // it computes the 35 x 19 level-(l+1) pixels its own tile needs (the 3-pixel rim is recomputed by the neighbours: +30 % work on
@@ -229,8 +233,8 @@ __global__ __launch_bounds__(256) void k_ingest_pyr1(DevBuffers d, const uint8_t
 // REFLECT_101 folds them onto positions inside the tile.
 #define P2_TW 16
 #define P2_TH 8
-__global__ __launch_bounds__(256) void k_pyrdown2(DevBuffers d, int level) {
-    const int plane = blockIdx.z % d.CN, sc = blockIdx.z / d.CN;
+static __device__ __forceinline__ void pyrdown2_body(const DevBuffers& d, int level, int bx, int by, int bz) {
+    const int plane = bz % d.CN, sc = bz / d.CN;
     const int seq = sc / 2, cam = sc & 1;
     const LevelInfo ls = d.geom.lv[level], lm = d.geom.lv[level + 1], ld = d.geom.lv[level + 2];
     uint8_t* base = d.pyr + pyr_index(d, seq, d.st[seq].slot_t1, cam) + (size_t)plane * d.geom.pyr_bytes;
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256) void k_pyrdown2(DevBuffers d, int level) {
     __shared__ unsigned short hrow[SH][MW + 1];
     __shared__ uint8_t mtile[MH][MW + 1];
     __shared__ unsigned short hrow2[MH][P2_TW];
-    const int ox = blockIdx.x * P2_TW, oy = blockIdx.y * P2_TH;  // level l+2
+    const int ox = bx * P2_TW, oy = by * P2_TH;                  // level l+2
     const int mx0 = 2 * ox - 2, my0 = 2 * oy - 2;                // level l+1
     const int sx0 = 2 * mx0 - 2, sy0 = 2 * my0 - 2;              // level l
     for (int i = threadIdx.x; i < SW * SH; i += 256) {
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(256) void k_pyrdown2(DevBuffers d, int level) {
         }
     }
 }
+__global__ __launch_bounds__(256) void k_pyrdown2(DevBuffers d, int level) { pyrdown2_body(d, level, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // levels first .. nlevels-1 from level first-1: pairs of levels per launch where two remain
 static void launch_pyramid_from(const DevBuffers& d, int first, hipStream_t st) {
@@ -408,28 +413,30 @@ static __device__ __forceinline__ void offer_tracks(const DevBuffers& d, int seq
 // MODE 0: frame pipeline, survivors go straight to the bucket keys (features_per_bucket == 1).  MODE 1: one image -> score map
 // (stage API).  MODE 2: frame pipeline -> per-sequence score map (features_per_bucket > 1: the general walk needs the keypoint list).
 template <int MODE>
-__global__ __launch_bounds__(256) void k_fast(const uint8_t* img_single, int w_single, int h_single, uint8_t* score_out,
-                                              DevBuffers d, int pass, int threshold) {
+static __device__ __forceinline__ void fast_body(const uint8_t* img_single, int w_single, int h_single, uint8_t* score_out,
+                                                 const DevBuffers& d, int pass, int threshold, int bx, int by, int bz, int gdx, int gdy) {
     constexpr bool TO_BUCKETS = MODE == 0;
     __shared__ __attribute__((aligned(4))) uint8_t pix[FT_PH][FT_PW + 4];
     __shared__ uint8_t sc[FT_SH][FT_SW + 2];
     __shared__ unsigned short cand[FT_SH * FT_SW];               // screened pixels of the tile (order is irrelevant)
     __shared__ int ncand;
-    const int seq = blockIdx.z;
+    const int seq = bz;
     int W, H; const uint8_t* img;
     if (MODE != 1) {
         const SeqState& s = d.st[seq];
-        if (pass == 0 ? !s.active : !s.do_second) return;
+        // Pass 0 reads nothing the per-frame reset writes (`active` is frame_id > 0, `n_old` is n_feat until the first emit), so
+        // that it may run in the SAME launch as the ingest blocks one of whose threads performs that reset (k_front_a).
+        if (pass == 0 ? !(s.frame_id > 0) : !s.do_second) return;
         W = d.geom.W; H = d.geom.H;
         // FAST runs on the PREVIOUS left image (vo.cpp:325); for a BGR context on the byte image cv::FAST really scans
         img = d.CN == 3 ? d.fastimg + fastimg_index(d, seq, s.slot_img_t0) : d.pyr + pyr_index(d, seq, s.slot_img_t0, 0);
         if (MODE == 2) score_out = d.score + (size_t)seq * W * H;
         if (TO_BUCKETS && pass == 0)                                 // the existing tracks enter the grid here (no launch of their own)
-            offer_tracks(d, seq, s.feat_buf, s.n_feat, (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x, gridDim.x * gridDim.y * 256);
+            offer_tracks(d, seq, s.feat_buf, s.n_feat, (by * gdx + bx) * 256 + threadIdx.x, gdx * gdy * 256);
     } else { W = w_single; H = h_single; img = img_single; }
     if (threshold < 0) threshold = 0;
     if (threshold > 255) threshold = 255;
-    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    const int x0 = bx * FT_W, y0 = by * FT_H;
     if (x0 >= 4 && y0 >= 4 && x0 - 4 + FT_PW <= W && y0 - 4 + FT_PH <= H) {
         // interior tile: 18 unaligned dword loads per row instead of 72 guarded byte loads
         static_assert(FT_PW % 4 == 0, "tile rows are whole dwords");
@@ -487,7 +494,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* img_single, int w_s
                 int bh = (int)((float)gy / (float)d.bucket_h), bw = (int)((float)gx / (float)d.bucket_w);
                 if (bh >= d.cfg.bucket_start_row && bh < d.cfg.buckets_along_height && bw < d.cfg.buckets_along_width && 0 < d.cfg.age_threshold) {
                     int score = 0 + (s - d.cfg.fast_threshold) / 20;                       // feature_set.cpp:16-18
-                    unsigned order = (unsigned)d.st[seq].n_old + (unsigned)(gy * W + gx);     // raster rank keeps cv::FAST's output order
+                    const unsigned n_old = pass == 0 ? (unsigned)d.st[seq].n_feat : (unsigned)d.st[seq].n_old;   // pass 0: the set is still the old one
+                    unsigned order = n_old + (unsigned)(gy * W + gx);                      // raster rank keeps cv::FAST's output order
                     bucket_offer(d, seq, bh, bw, make_bucket_key(score, order, s));
                 }
             }
@@ -495,6 +503,11 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* img_single, int w_s
             score_out[(size_t)gy * W + gx] = keep ? (uint8_t)s : (uint8_t)0;
         }
     }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_fast(const uint8_t* img_single, int w_single, int h_single, uint8_t* score_out,
+                                              DevBuffers d, int pass, int threshold) {
+    fast_body<MODE>(img_single, w_single, h_single, score_out, d, pass, threshold, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }
 
 void launch_fast_score_map(const uint8_t* img_dev, int w, int h, int threshold, uint8_t* score_dev, hipStream_t st) {
@@ -552,8 +565,7 @@ void launch_score_compact(const uint8_t* score_dev, int w, int h, int cap, int* 
 // pass kept too few features (vo.cpp:327) that last block also offers the new set to the grid for the second pass.
 #define EMIT_THREADS 256
 #define EMIT_WAVES (EMIT_THREADS / 64)
-__global__ __launch_bounds__(EMIT_THREADS) void k_bucket_emit(DevBuffers d, int pass) {
-    const int seq = blockIdx.y, row = blockIdx.x;
+static __device__ __forceinline__ void bucket_emit_body(const DevBuffers& d, int pass, int row, int seq, int n_rows) {
     SeqState& s = d.st[seq];
     if (pass == 0 ? !s.active : !s.do_second) return;
     __shared__ int sh_before[EMIT_WAVES], sh_all[EMIT_WAVES], sh_cnt[EMIT_WAVES], sh_last;
@@ -606,7 +618,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_bucket_emit(DevBuffers d, int 
     const bool second = pass == 0 && total < d.cfg.pre_matching_feature_threshold;               // vo.cpp:327
     if (second) __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) sh_last = atomicAdd(&d.emit_ticket[seq], 1) == (int)gridDim.x - 1;
+    if (threadIdx.x == 0) sh_last = atomicAdd(&d.emit_ticket[seq], 1) == n_rows - 1;
     __syncthreads();
     if (!sh_last) return;
     if (second) __threadfence();
@@ -623,6 +635,42 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_bucket_emit(DevBuffers d, int 
         __syncthreads();
         offer_tracks(d, seq, fb ^ 1, total, threadIdx.x, EMIT_THREADS);
     }
+}
+__global__ __launch_bounds__(EMIT_THREADS) void k_bucket_emit(DevBuffers d, int pass) { bucket_emit_body(d, pass, blockIdx.x, blockIdx.y, gridDim.x); }
+
+// ---- the front of a lone stream's frame in two launches instead of four.  Ingest + pyramid and detection are independent
+// chains (FAST runs on the PREVIOUS left image, vo.cpp:325): on a nearly empty GPU their kernels ran one after the other, each
+// a few microseconds of work behind a launch.  k_front_a = {ingest + level 1 (with the per-frame reset)  ||  FAST pass 0},
+// k_front_b = {levels 2 and 3  ||  emit of pass 0}: blocks of both kinds in one grid, told apart by their linear index; the
+// two halves of a launch touch disjoint data (pass 0 of k_fast reads no field the reset writes).  Lone-stream contexts only
+// (SVO_LONE_MAX_SEQ): with many sequences every kernel fills the GPU by itself and the separate launches stay.
+static_assert(EMIT_THREADS == 256, "k_front_b runs emit blocks beside 256-thread pyramid blocks");
+__global__ __launch_bounds__(256) void k_front_a(DevBuffers d, const uint8_t* const* srcs, int stride, int ax, int ay, int n_a, int fx, int fy, int threshold) {
+    const int i = blockIdx.x;
+    if (i < n_a) { ingest_pyr1_body(d, srcs, stride, 1, i % ax, (i / ax) % ay, i / (ax * ay)); return; }
+    const int j = i - n_a;
+    fast_body<0>(nullptr, 0, 0, nullptr, d, 0, threshold, j % fx, (j / fx) % fy, j / (fx * fy), fx, fy);
+}
+__global__ __launch_bounds__(256) void k_front_b(DevBuffers d, int px, int py, int n_p, int n_rows) {
+    const int i = blockIdx.x;
+    if (i < n_p) { pyrdown2_body(d, 1, i % px, (i / px) % py, i / (px * py)); return; }
+    const int j = i - n_p;
+    bucket_emit_body(d, 0, j % n_rows, j / n_rows, n_rows);
+}
+// true if the fused front applies to this context (then it has been launched): single-channel, four pyramid levels or more,
+// one feature per bucket, a lone stream
+bool launch_front_fused(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride, hipStream_t st) {
+    static const bool off = getenv("SVO_FRONT_FUSED") && atoi(getenv("SVO_FRONT_FUSED")) == 0;
+    if (off || d.B > SVO_LONE_MAX_SEQ || d.CN != 1 || d.geom.nlevels < 4 || d.cfg.features_per_bucket != 1) return false;
+    const int ax = (d.geom.lv[1].w + PD_TW - 1) / PD_TW, ay = (d.geom.lv[1].h + PD_TH - 1) / PD_TH, n_a = ax * ay * d.B * 2;
+    const int fx = (d.geom.W + FT_W - 1) / FT_W, fy = (d.geom.H + FT_H - 1) / FT_H, n_f = fx * fy * d.B;
+    hipLaunchKernelGGL(k_front_a, dim3(n_a + n_f), dim3(256), 0, st, d, left_right_dev_ptrs, stride, ax, ay, n_a, fx, fy, d.cfg.fast_threshold);
+    const int px = (d.geom.lv[3].w + P2_TW - 1) / P2_TW, py = (d.geom.lv[3].h + P2_TH - 1) / P2_TH, n_p = px * py * d.B * 2;
+    const int n_rows = d.cfg.buckets_along_height;
+    hipLaunchKernelGGL(k_front_b, dim3(n_p + n_rows * d.B), dim3(256), 0, st, d, px, py, n_p, n_rows);
+    launch_pyramid_from(d, 4, st);                                    // a fifth level and beyond (cfg3)
+    launch_detect(d, 1, -1, st);                                      // the second pass exits at once unless needed (vo.cpp:327-332)
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------
