@@ -329,9 +329,10 @@ static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_e
         g.armed = true;
     }
     launch_compact(d, s);
-    launch_triangulate(d, s);
-    if (with_events) HIPCHK(hipEventRecord(c->ev_tri[slot], s));
-    launch_pnp(d, s);
+    const bool tri_epnp = launch_triangulate_epnp_fused(d, s);          // lone stream: the first EPnP chunk runs beside the triangulation
+    if (!tri_epnp) launch_triangulate(d, s);
+    if (with_events) HIPCHK(hipEventRecord(c->ev_tri[slot], s));       // (fused: the stage timers count that chunk with the triangulation)
+    launch_pnp(d, s, tri_epnp);
     launch_frame_end(d, slot, s);      // writes the result records straight into the pinned host ring (d.results is host memory mapped into the device)
     return SVO_OK;
 }

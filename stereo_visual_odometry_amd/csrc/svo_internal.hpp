@@ -111,7 +111,8 @@ void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s
 bool launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t s, int early_out);   // false: no kernel built for this (window, lanes, channels) — nothing ran
 void launch_compact(const DevBuffers& d, hipStream_t s);
 void launch_triangulate(const DevBuffers& d, hipStream_t s);
-void launch_pnp(const DevBuffers& d, hipStream_t s);                   // expects the subsets drawn (launch_triangulate does it)
+void launch_pnp(const DevBuffers& d, hipStream_t s, bool first_chunk_solved = false);   // expects the subsets drawn (launch_triangulate / k_compact do it)
+bool launch_triangulate_epnp_fused(const DevBuffers& d, hipStream_t s);   // lone stream: triangulation || first EPnP chunk in one launch; false = not applicable
 void launch_pnp_subsets(const DevBuffers& d, hipStream_t s);
 void launch_pnp_p3p(const DevBuffers& d, hipStream_t s);                // exactly four points: one P3P, no RANSAC (stage API only)
 void launch_inverse_transform(const double* R, const double* t, double* T, hipStream_t s);   // device pointers
@@ -134,3 +135,42 @@ bool lk_window_supported(int win);
 int lk_registers_left(const DevBuffers& d);   // VGPRs per SIMD lane beside a full set of this context's LK waves (-1: unknown)
 bool lk_window_supported_cn(int win, int cn);
 float lk_mineig_cut(int win, double min_eig_threshold);
+
+// ------------------------------------------------------------------------------------------------ subsets (cv::RNG, getSubset)
+// All K 5-subsets of one sequence, drawn with cv::RNG's multiply-with-carry recurrence from the seed (uint64)-1; the number
+// of draws never depends on model quality.  uniform(0, n) = next() % n: the remainder is taken through the 64-bit reciprocal
+// ceil(2^64 / n) (exact for 32-bit operands: the error term x e / (n 2^64) stays below 2^-32 < 1/n), 6 instructions instead
+// of the 32-bit division sequence.
+// Draws subsets [s.pnp_drawn, upto) and leaves the generator state in s.pnp_rng: the first chunk is drawn beside the
+// triangulation, the rest only as far as the adaptive loop can still reach (k_pnp_decide) — with a static scene that is never.
+static __device__ inline void pnp_draw_subsets(const DevBuffers& d, SeqState& s, int seq, int upto) {
+    const unsigned n = (unsigned)s.n_tracks;
+    if (n < 2) return;
+    if (upto > d.K) upto = d.K;
+    int* out = d.subsets + (size_t)seq * d.K * 5;
+    if (n == 5) {                                                    // model_points == npoints: one direct solve on all five (solvepnp.cpp)
+        for (int i = 0; i < 5; i++) out[i] = i;
+        s.pnp_drawn = d.K;
+        return;
+    }
+    unsigned long long state = s.pnp_drawn == 0 ? 0xFFFFFFFFFFFFFFFFull : s.pnp_rng;      // RNG rng((uint64)-1)
+    const unsigned long long recip = 0xFFFFFFFFFFFFFFFFull / n + 1ull;
+    for (int it = s.pnp_drawn; it < upto; it++) {
+        int idx[5];
+        for (int i = 0; i < 5; i++) {
+            int v; bool dup;
+            do {
+                state = (unsigned long long)(unsigned)state * 4164903690ull + (unsigned)(state >> 32);
+                const unsigned x = (unsigned)state;
+                v = (int)(x - (unsigned)__umul64hi((unsigned long long)x, recip) * n);
+                dup = false;
+                for (int k = 0; k < i; k++) dup |= (idx[k] == v);
+            } while (dup);
+            idx[i] = v;
+        }
+        for (int i = 0; i < 5; i++) out[it * 5 + i] = idx[i];
+    }
+    if (upto > s.pnp_drawn) s.pnp_drawn = upto;
+    s.pnp_rng = state;
+}
+

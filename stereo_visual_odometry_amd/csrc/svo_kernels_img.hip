@@ -926,6 +926,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_compact(DevBuffers d) {
         }
         int thr = d.cfg.features_threshold > 4 ? d.cfg.features_threshold : 4;
         if (s.n_tracks <= thr) s.fail_reason = 2;                  // vo.cpp:82-84
+        // a lone stream's first RANSAC chunk shares a launch with the triangulation (k_tri_epnp): its subsets — a function of the
+        // track count alone — are drawn here, one launch earlier (many-sequence contexts: the spare block of k_triangulate)
+        if (d.B <= SVO_LONE_MAX_SEQ && s.fail_reason == 0) pnp_draw_subsets(d, s, seq, pnp_first_chunk(d));
     }
 }
 void launch_compact(const DevBuffers& d, hipStream_t st) {

@@ -101,22 +101,10 @@ static __device__ void svd4_null_vector(const double (&A)[4][4], double (&X)[4])
 
 // The last block of every sequence does not triangulate: its first lane draws the RANSAC subsets (they depend on the
 // track count only), so the serial RNG walk hides under the triangulation instead of being a launch of its own.
-static __device__ void pnp_draw_subsets(const DevBuffers& d, SeqState& s, int seq, int upto);
 // `lanes` tracks per wave: 64 when many sequences fill the GPU; 16 when a single stream runs alone — the Jacobi sweeps of a wave
 // last as long as its slowest lane needs, so with the GPU nearly empty fewer tracks per wave shorten the kernel (same results).
-static __device__ __forceinline__ void triangulate_body(const DevBuffers& d, int lanes) {
-    const int seq = blockIdx.y;
-    SeqState& s = d.st[seq];
-    if (!seq_live(s)) return;
-    if (blockIdx.x == gridDim.x - 1) {
-        if (threadIdx.x == 0) pnp_draw_subsets(d, s, seq, pnp_first_chunk(d));
-        return;
-    }
-    if ((int)threadIdx.x >= lanes) return;
-    const int i = blockIdx.x * lanes + threadIdx.x;
-    if (i >= s.n_tracks) return;
-    const size_t o = (size_t)seq * d.CAP + i;
-    const float2 pl = d.tl0[o], pr = d.tr0[o];
+// one track: the DLT system of the two views (vo.cpp:89-91), its null vector, dehomogenised to f32 (vo.cpp:93-94)
+static __device__ __forceinline__ void triangulate_point(const SeqState& s, float2 pl, float2 pr, float (&w)[3]) {
     double A[4][4], V[4];
     const double xl = pl.x, yl = pl.y, xr = pr.x, yr = pr.y;
 #pragma unroll
@@ -129,7 +117,24 @@ static __device__ __forceinline__ void triangulate_body(const DevBuffers& d, int
     svd4_null_vector(A, V);
     const float X = (float)V[0], Y = (float)V[1], Z = (float)V[2], Wh = (float)V[3];           // 4xN result is CV_32F
     const float scale = Wh != 0.f ? 1.f / Wh : 1.f;                                             // convertPointsFromHomogeneous
-    d.world[3 * o] = X * scale; d.world[3 * o + 1] = Y * scale; d.world[3 * o + 2] = Z * scale;
+    w[0] = X * scale; w[1] = Y * scale; w[2] = Z * scale;
+}
+// spare: the last block (bx == nblocks - 1) draws the RANSAC subsets instead of triangulating (many-sequence contexts; a
+// lone stream's k_compact has drawn them already, and its triangulation shares a launch with the first EPnP chunk, k_tri_epnp)
+static __device__ __forceinline__ void triangulate_body(const DevBuffers& d, int lanes, int bx, int seq, int nblocks, bool spare) {
+    SeqState& s = d.st[seq];
+    if (!seq_live(s)) return;
+    if (spare && bx == nblocks - 1) {
+        if (threadIdx.x == 0) pnp_draw_subsets(d, s, seq, pnp_first_chunk(d));
+        return;
+    }
+    if ((int)threadIdx.x >= lanes) return;
+    const int i = bx * lanes + threadIdx.x;
+    if (i >= s.n_tracks) return;
+    const size_t o = (size_t)seq * d.CAP + i;
+    float w[3];
+    triangulate_point(s, d.tl0[o], d.tr0[o], w);
+    d.world[3 * o] = w[0]; d.world[3 * o + 1] = w[1]; d.world[3 * o + 2] = w[2];
 }
 // Two builds (here and for EPnP and the final refine below).  An LK wave holds 104 registers and four of them share a SIMD: 96
 // registers stay free.  A kernel that needs more cannot start beside the LK grid of another context — it waits until that grid
@@ -137,8 +142,8 @@ static __device__ __forceinline__ void triangulate_body(const DevBuffers& d, int
 // with it.  The `_lean` builds are capped at 96 registers (amdgpu_num_vgpr counts VGPR + AGPR pairs on gfx950) and spill to
 // scratch: slower alone (32 sequences, one context: EPnP 202 -> 286 us, final 90 -> 362 us), but they run under the other
 // context's LK instead of after it.  Used when several many-sequence contexts share the device (DevBuffers::co_resident).
-__global__ __launch_bounds__(64) void k_triangulate(DevBuffers d, int lanes) { triangulate_body(d, lanes); }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void k_triangulate_lean(DevBuffers d, int lanes) { triangulate_body(d, lanes); }
+__global__ __launch_bounds__(64) void k_triangulate(DevBuffers d, int lanes) { triangulate_body(d, lanes, blockIdx.x, blockIdx.y, gridDim.x, true); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void k_triangulate_lean(DevBuffers d, int lanes) { triangulate_body(d, lanes, blockIdx.x, blockIdx.y, gridDim.x, true); }
 void launch_triangulate(const DevBuffers& d, hipStream_t st) {
     const bool lean = d.co_resident;
     const int lanes = d.B > SVO_LONE_MAX_SEQ ? 64 : 16;
@@ -146,44 +151,7 @@ void launch_triangulate(const DevBuffers& d, hipStream_t st) {
     else hipLaunchKernelGGL(k_triangulate, dim3((d.CAP + lanes - 1) / lanes + 1, d.B), dim3(64), 0, st, d, lanes);
 }
 
-// ------------------------------------------------------------------------------------------------ subsets (cv::RNG, getSubset)
-// All K 5-subsets of one sequence, drawn with cv::RNG's multiply-with-carry recurrence from the seed (uint64)-1; the number
-// of draws never depends on model quality.  uniform(0, n) = next() % n: the remainder is taken through the 64-bit reciprocal
-// ceil(2^64 / n) (exact for 32-bit operands: the error term x e / (n 2^64) stays below 2^-32 < 1/n), 6 instructions instead
-// of the 32-bit division sequence.
-// Draws subsets [s.pnp_drawn, upto) and leaves the generator state in s.pnp_rng: the first chunk is drawn beside the
-// triangulation, the rest only as far as the adaptive loop can still reach (k_pnp_decide) — with a static scene that is never.
-static __device__ void pnp_draw_subsets(const DevBuffers& d, SeqState& s, int seq, int upto) {
-    const unsigned n = (unsigned)s.n_tracks;
-    if (n < 2) return;
-    if (upto > d.K) upto = d.K;
-    int* out = d.subsets + (size_t)seq * d.K * 5;
-    if (n == 5) {                                                    // model_points == npoints: one direct solve on all five (solvepnp.cpp)
-        for (int i = 0; i < 5; i++) out[i] = i;
-        s.pnp_drawn = d.K;
-        return;
-    }
-    unsigned long long state = s.pnp_drawn == 0 ? 0xFFFFFFFFFFFFFFFFull : s.pnp_rng;      // RNG rng((uint64)-1)
-    const unsigned long long recip = 0xFFFFFFFFFFFFFFFFull / n + 1ull;
-    for (int it = s.pnp_drawn; it < upto; it++) {
-        int idx[5];
-        for (int i = 0; i < 5; i++) {
-            int v; bool dup;
-            do {
-                state = (unsigned long long)(unsigned)state * 4164903690ull + (unsigned)(state >> 32);
-                const unsigned x = (unsigned)state;
-                v = (int)(x - (unsigned)__umul64hi((unsigned long long)x, recip) * n);
-                dup = false;
-                for (int k = 0; k < i; k++) dup |= (idx[k] == v);
-            } while (dup);
-            idx[i] = v;
-        }
-        for (int i = 0; i < 5; i++) out[it * 5 + i] = idx[i];
-    }
-    if (upto > s.pnp_drawn) s.pnp_drawn = upto;
-    s.pnp_rng = state;
-}
-
+// (pnp_draw_subsets — cv::RNG + getSubset — lives in svo_internal.hpp: k_compact draws the first chunk for lone-stream contexts)
 // stand-alone launch for callers that enter at launch_pnp without a triangulation before it (svo_camera_to_world)
 __global__ void k_pnp_subsets(DevBuffers d) {
     const int seq = blockIdx.x * blockDim.x + threadIdx.x;
@@ -641,34 +609,36 @@ static __device__ __attribute__((always_inline)) void epnp_branch(double* ar, in
 
 // Hypotheses [h0, h1).  The first chunk (h0 == 0) is always solved; later chunks only up to s.pnp_need, the bound the
 // adaptive loop had reached after the first chunk (the bound only ever shrinks, so nothing beyond it can be consulted).
-template <int G>                          // lanes per hypothesis: 8 (six rotate a pair each) or 16 (twelve: two lanes per pair)
-static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0, int h1, double* arena) {
+// OWN_TRI: the hypothesis triangulates its five points itself (lanes 0..4, the same triangulate_point, hence the same floats)
+// instead of reading d.world — so that the first chunk can share a launch with the triangulation of all tracks (k_tri_epnp).
+template <int G, bool OWN_TRI = false>    // lanes per hypothesis: 8 (six rotate a pair each) or 16 (twelve: two lanes per pair)
+static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0, int h1, double* arena, int bx, int seq) {
     constexpr int HPB = 64 / G;
-    const int seq = blockIdx.y;
     const SeqState& s = d.st[seq];
     if (!seq_live(s)) return;
     int hend = h0 > 0 ? (s.pnp_need < h1 ? s.pnp_need : h1) : h1;
     if (s.n_tracks == 5 && hend > 1) hend = 1;                          // five points: a single direct EPnP, no RANSAC
-    if (h0 + (int)blockIdx.x * HPB >= hend) return;                     // block-uniform
+    if (h0 + bx * HPB >= hend) return;                                  // block-uniform
     const int g = threadIdx.x / G, q = threadIdx.x % G;
-    const int h = h0 + blockIdx.x * HPB + g;
+    const int h = h0 + bx * HPB + g;
     const bool valid = h < hend;
     double* ar = arena + g * EP_STRIDE;
     const double fx = s.K[0], fy = s.K[4], cx = s.K[2], cy = s.K[5];
-    if (valid && q == 0) {
+    if (valid && q < 5) {                                               // one lane per point of the subset
         const size_t o = (size_t)seq * d.CAP;
-        const int* idx = d.subsets + ((size_t)seq * d.K + h) * 5;
+        const int k = d.subsets[((size_t)seq * d.K + h) * 5 + q];
         const double ifx = 1. / fx, ify = 1. / fy;
-        for (int i = 0; i < 5; i++) {
-            int k = idx[i];
-            ar[EA_PWS + 3 * i] = d.world[3 * (o + k)]; ar[EA_PWS + 3 * i + 1] = d.world[3 * (o + k) + 1]; ar[EA_PWS + 3 * i + 2] = d.world[3 * (o + k) + 2];
-            float2 c = d.tl1[o + k];
-            // undistortPoints on CV_32FC2 with zero distortion (normalise in f64, store f32), then epnp re-applies fu, uc
-            float xn = (float)(((double)c.x - cx) * ifx), yn = (float)(((double)c.y - cy) * ify);
-            ar[EA_US + 2 * i] = (double)xn * fx + cx; ar[EA_US + 2 * i + 1] = (double)yn * fy + cy;
-        }
-        epnp_setup(ar, fx, fy, cx, cy);
+        float w[3];
+        if (OWN_TRI) triangulate_point(s, d.tl0[o + k], d.tr0[o + k], w);
+        else { w[0] = d.world[3 * (o + k)]; w[1] = d.world[3 * (o + k) + 1]; w[2] = d.world[3 * (o + k) + 2]; }
+        ar[EA_PWS + 3 * q] = w[0]; ar[EA_PWS + 3 * q + 1] = w[1]; ar[EA_PWS + 3 * q + 2] = w[2];
+        const float2 c = d.tl1[o + k];
+        // undistortPoints on CV_32FC2 with zero distortion (normalise in f64, store f32), then epnp re-applies fu, uc
+        const float xn = (float)(((double)c.x - cx) * ifx), yn = (float)(((double)c.y - cy) * ify);
+        ar[EA_US + 2 * q] = (double)xn * fx + cx; ar[EA_US + 2 * q + 1] = (double)yn * fy + cy;
     }
+    __syncthreads();
+    if (valid && q == 0) epnp_setup(ar, fx, fy, cx, cy);
     __syncthreads();
     if (valid) for (int i = q; i < 12; i += G) epnp_setup_row(ar, i);
     __syncthreads();
@@ -738,11 +708,20 @@ static __device__ __forceinline__ void pnp_epnp_body(const DevBuffers& d, int h0
 // register budget to the occupancy the LDS allows and ignores the cap) is for contexts that share the GPU with another's LK.
 __global__ __launch_bounds__(64) void k_pnp_epnp(DevBuffers d, int h0, int h1) {
     __shared__ double arena[(64 / EP_G_LONE) * EP_STRIDE];
-    pnp_epnp_body<EP_G_LONE>(d, h0, h1, arena);
+    pnp_epnp_body<EP_G_LONE>(d, h0, h1, arena, blockIdx.x, blockIdx.y);
+}
+// Lone stream: the triangulation of all tracks and the FIRST chunk of EPnP hypotheses in one launch.  On a nearly empty GPU the
+// two ran one after the other (36 + 140 us); a hypothesis needs the world points of its own five tracks only, which its lanes
+// 0..4 now compute themselves, so the hypothesis blocks start at once and the triangulation blocks (whose output the SCORING
+// needs, one launch later) run beside them.  The subsets were drawn by k_compact.  blockIdx.x < n_e: hypothesis block.
+__global__ __launch_bounds__(64) void k_tri_epnp(DevBuffers d, int lanes, int n_e, int c0) {
+    __shared__ double arena[(64 / EP_G_LONE) * EP_STRIDE];
+    if ((int)blockIdx.x < n_e) pnp_epnp_body<EP_G_LONE, true>(d, 0, c0, arena, blockIdx.x, blockIdx.y);
+    else triangulate_body(d, lanes, (int)blockIdx.x - n_e, blockIdx.y, 0, false);
 }
 extern __shared__ double epnp_arena_dyn[];                         // (64 / EP_G) * EP_STRIDE doubles, given at launch
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void k_pnp_epnp_lean(DevBuffers d, int h0, int h1) {
-    pnp_epnp_body<EP_G>(d, h0, h1, epnp_arena_dyn);
+    pnp_epnp_body<EP_G>(d, h0, h1, epnp_arena_dyn, blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------ hypothesis scoring
@@ -1401,7 +1380,17 @@ void launch_inverse_transform(const double* R, const double* t, double* T, hipSt
     hipLaunchKernelGGL(k_inverse_transform, dim3(1), dim3(64), 0, st, R, t, T);
 }
 
-void launch_pnp(const DevBuffers& d, hipStream_t st) {
+// lone-stream frame pipeline: triangulation || first EPnP chunk (k_tri_epnp); true if launched (then call launch_pnp(.., true))
+bool launch_triangulate_epnp_fused(const DevBuffers& d, hipStream_t st) {
+    static const bool off = getenv("SVO_TRI_EPNP_FUSED") && atoi(getenv("SVO_TRI_EPNP_FUSED")) == 0;
+    if (off || d.B > SVO_LONE_MAX_SEQ || d.co_resident) return false;
+    const int lanes = 16, c0 = pnp_first_chunk(d), hpb = 64 / EP_G_LONE;
+    const int n_e = (c0 + hpb - 1) / hpb, n_t = (d.CAP + lanes - 1) / lanes;
+    hipLaunchKernelGGL(k_tri_epnp, dim3(n_e + n_t, d.B), dim3(64), 0, st, d, lanes, n_e, c0);
+    return true;
+}
+
+void launch_pnp(const DevBuffers& d, hipStream_t st, bool first_chunk_solved) {
     // the subsets were drawn by the last block of k_triangulate (stage entry points go through launch_triangulate too)
     const int c0 = pnp_first_chunk(d);
     const bool lean = d.co_resident;                                 // see k_triangulate_lean
@@ -1414,7 +1403,8 @@ void launch_pnp(const DevBuffers& d, hipStream_t st) {
         }
     }
     const int hpb = 64 / (lean ? EP_G : EP_G_LONE);
-    if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((c0 + hpb - 1) / hpb, d.B), dim3(64), EP_LEAN_LDS, st, d, 0, c0);
+    if (first_chunk_solved) { /* k_tri_epnp did it */ }
+    else if (lean) hipLaunchKernelGGL(k_pnp_epnp_lean, dim3((c0 + hpb - 1) / hpb, d.B), dim3(64), EP_LEAN_LDS, st, d, 0, c0);
     else hipLaunchKernelGGL(k_pnp_epnp, dim3((c0 + hpb - 1) / hpb, d.B), dim3(64), 0, st, d, 0, c0);
     hipLaunchKernelGGL(k_pnp_score, dim3(c0, d.B), dim3(256), 0, st, d, 0, c0);
     if (d.K > c0) {
