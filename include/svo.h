@@ -166,7 +166,9 @@ int svo_set_stage_timing(svo_context* ctx, int on);
 /* Per-stage HIP-event milliseconds of the last collected frame (all sequences of the context together), in pipeline order:
  * ms[0] ingest + pyramids (vo.cpp:74-75, 200-201)   ms[1] FAST + bucketing, both passes (vo.cpp:325-332)
  * ms[2] the four LK passes + masks (vo.cpp:203-230, 341-359)   ms[3] compaction + triangulation (vo.cpp:233-238, 360-364, 89-94)
- * ms[4] RANSAC-PnP, inlier update, gates, result record (vo.cpp:101-136).  The reference has no timers. */
+ * ms[4] RANSAC-PnP, inlier update, gates, result record (vo.cpp:101-136).  The reference has no timers.
+ * A lone-stream context (<= 8 sequences) runs independent stages in shared launches: ms[0] then covers ingest + pyramids AND the
+ * first detection pass (ms[1]: only the second pass), ms[3] covers compaction, triangulation AND the first EPnP chunk. */
 int svo_get_stage_timing(svo_context* ctx, float ms[5]);
 void* svo_get_stream(svo_context* ctx);   /* hipStream_t the context launches on */
 
