@@ -174,3 +174,60 @@ static __device__ inline void pnp_draw_subsets(const DevBuffers& d, SeqState& s,
     s.pnp_rng = state;
 }
 
+// The first chunk of a lone stream, drawn by the 64 lanes of ONE wave (k_compact's first) from the table of raw generator states
+// (svo_rng_table.hpp): lane h takes subset h at its no-duplicate position (raw draws 5h .. 5h+4), which is right for every subset
+// up to the first one that meets a duplicate (getSubset redraws and the stream shifts); from that subset on lane 0 walks the
+// stream serially, exactly as pnp_draw_subsets does (from the table while it lasts).  Same subsets, same generator state
+// afterwards.  With ~900 tracks no subset of the 32 has a duplicate in two frames of three.  Call with all 64 lanes.
+#include "svo_rng_table.hpp"
+static __device__ inline void pnp_draw_first_chunk_wave(const DevBuffers& d, SeqState& s, int seq, int n_tracks, int upto) {
+    const int lane = threadIdx.x & 63;
+    const unsigned n = (unsigned)n_tracks;
+    if (upto > d.K) upto = d.K;
+    if (n < 6 || upto > 32 || upto * 5 + 8 > SVO_RNG_TABLE_N) {                 // n == 5: the direct solve; tiny sets: not worth a second path
+        if (lane == 0) { s.n_tracks = n_tracks; pnp_draw_subsets(d, s, seq, upto); }
+        return;
+    }
+    int* out = d.subsets + (size_t)seq * d.K * 5;
+    const unsigned long long recip = 0xFFFFFFFFFFFFFFFFull / n + 1ull;
+    int v[5]; bool dup = false;
+    if (lane < upto) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const unsigned x = (unsigned)SVO_RNG_STATES[lane * 5 + i];
+            v[i] = (int)(x - (unsigned)__umul64hi((unsigned long long)x, recip) * n);
+        }
+#pragma unroll
+        for (int i = 1; i < 5; i++)
+#pragma unroll
+            for (int k = 0; k < i; k++) dup |= v[i] == v[k];
+    }
+    const unsigned long long dm = __ballot(dup);
+    const int first_bad = dm ? __ffsll((long long)dm) - 1 : upto;              // subsets [0, first_bad) stand as drawn
+    if (lane < first_bad) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) out[lane * 5 + i] = v[i];
+    }
+    if (lane == 0) {
+        int t = first_bad * 5;                                                 // raw draws consumed so far
+        unsigned long long state = t > 0 ? SVO_RNG_STATES[t - 1] : 0xFFFFFFFFFFFFFFFFull;
+        for (int it = first_bad; it < upto; it++) {
+            int idx[5];
+            for (int i = 0; i < 5; i++) {
+                int w; bool dd;
+                do {
+                    state = t < SVO_RNG_TABLE_N ? SVO_RNG_STATES[t] : (unsigned long long)(unsigned)state * 4164903690ull + (unsigned)(state >> 32);
+                    t++;
+                    const unsigned x = (unsigned)state;
+                    w = (int)(x - (unsigned)__umul64hi((unsigned long long)x, recip) * n);
+                    dd = false;
+                    for (int k = 0; k < i; k++) dd |= (idx[k] == w);
+                } while (dd);
+                idx[i] = w;
+            }
+            for (int i = 0; i < 5; i++) out[it * 5 + i] = idx[i];
+        }
+        s.pnp_drawn = upto;
+        s.pnp_rng = state;
+    }
+}

@@ -926,9 +926,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_compact(DevBuffers d) {
         }
         int thr = d.cfg.features_threshold > 4 ? d.cfg.features_threshold : 4;
         if (s.n_tracks <= thr) s.fail_reason = 2;                  // vo.cpp:82-84
-        // a lone stream's first RANSAC chunk shares a launch with the triangulation (k_tri_epnp): its subsets — a function of the
-        // track count alone — are drawn here, one launch earlier (many-sequence contexts: the spare block of k_triangulate)
-        if (d.B <= SVO_LONE_MAX_SEQ && s.fail_reason == 0) pnp_draw_subsets(d, s, seq, pnp_first_chunk(d));
+    }
+    // a lone stream's first RANSAC chunk shares a launch with the triangulation (k_tri_epnp): its subsets — a function of the track
+    // count alone, which every thread of this block knows by now — are drawn here, one launch earlier, by the first wave
+    // (many-sequence contexts: the spare block of k_triangulate)
+    if (d.B <= SVO_LONE_MAX_SEQ && wv == 0 && n > 0) {
+        const int thr = d.cfg.features_threshold > 4 ? d.cfg.features_threshold : 4;
+        if (run > thr && s.active) pnp_draw_first_chunk_wave(d, s, seq, run, pnp_first_chunk(d));
     }
 }
 void launch_compact(const DevBuffers& d, hipStream_t st) {
