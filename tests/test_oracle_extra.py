@@ -135,3 +135,20 @@ def test_oracle_failure_gates():
     ok, T = vo.stereo_callback(seq.left[1], seq.right[1])
     # 0.4 m step: either still recovering from the stale pyramid (2) or rejected by the 0.1 m motion gate (4)
     assert not ok and vo.stats.fail_reason in (2, 4) and np.array_equal(T, np.eye(4))
+
+
+def test_rng_state_table_of_the_product_equals_the_published_recurrence():
+    """stereo_visual_odometry_amd/csrc/svo_rng_table.hpp holds the first 256 states of cv::RNG((uint64)-1) — k_compact draws a
+    lone stream's first RANSAC chunk from it.  Every entry must be what rand.cpp's multiply-with-carry recurrence gives
+    (state = (uint32)state * 4164903690 + (state >> 32)), and its low halves what the oracle's generator returns."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "stereo_visual_odometry_amd", "csrc", "svo_rng_table.hpp")).read()
+    vals = [int(v, 16) for v in re.findall(r"0x([0-9A-Fa-f]{16})ull", txt)]
+    assert len(vals) == 256
+    st = 0xFFFFFFFFFFFFFFFF
+    for v in vals:
+        st = ((st & 0xFFFFFFFF) * 4164903690 + (st >> 32)) & 0xFFFFFFFFFFFFFFFF
+        assert v == st
+    assert [v & 0xFFFFFFFF for v in vals[:64]] == orc.rng_sequence(64)
