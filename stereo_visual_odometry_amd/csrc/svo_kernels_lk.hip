@@ -889,6 +889,12 @@ static int lk_xcd_mapping() { static int v = -1; if (v < 0) { const char* e = ge
 // winSize is a mutable member in the reference (vo.h:251), so every square window from 5 to 31 is built: the tuned entries
 // first (lanes per feature chosen by measurement), then the generic one-wave-per-feature form for all other sizes — the same
 // code (LkLayout derives the segment shape from W), just not tuned.
+#ifdef SVO_LK_DEV_W21   // developer build (-DSVO_LK_DEV_W21): only the w = 21 grey default-mode kernel, compiles in seconds; never shipped
+#define LK_FOR_EACH_WINDOW(X) X(21, 64)
+#define LK_FOR_EACH_WINDOW_CN3(X)
+#define LK_FOR_EACH_WINDOW_FS(X)
+#define LK_FOR_EACH_WINDOW_FS_CN3(X)
+#else
 #define LK_FOR_EACH_WINDOW_TUNED(X) X(7, 16) X(7, 64) X(10, 16) X(10, 64) X(15, 32) X(15, 64) X(21, 64) X(21, 32) X(31, 64)
 #define LK_FOR_EACH_WINDOW_GENERIC(X) X(5, 64) X(6, 64) X(8, 64) X(9, 64) X(11, 64) X(12, 64) X(13, 64) X(14, 64) X(16, 64) X(17, 64) X(18, 64) \
     X(19, 64) X(20, 64) X(22, 64) X(23, 64) X(24, 64) X(25, 64) X(26, 64) X(27, 64) X(28, 64) X(29, 64) X(30, 64)
@@ -904,6 +910,7 @@ static int lk_xcd_mapping() { static int v = -1; if (v < 0) { const char* e = ge
     X(18, 64) X(19, 64) X(20, 64) X(21, 64) X(22, 64) X(23, 64) X(24, 64) X(25, 64) X(26, 64) X(27, 64) X(28, 64) X(29, 64) X(30, 64) X(31, 64)
 #define LK_FOR_EACH_WINDOW_FS_CN3(X) X(5, 64) X(6, 64) X(7, 64) X(8, 64) X(9, 64) X(10, 64) X(11, 64) X(12, 64) X(13, 64) X(14, 64) X(15, 64) X(16, 64) X(17, 64) \
     X(18, 64) X(19, 64) X(20, 64) X(21, 64)
+#endif
 
 // Smallest float x with (double)(float)(x / (2 w^2)) >= threshold — found by bisection over the floats in their numeric order
 // (IEEE f32 division on the host, the same operation the kernel would do).  +inf if no finite float qualifies.
