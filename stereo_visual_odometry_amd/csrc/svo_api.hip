@@ -55,19 +55,20 @@ extern "C" void svo_config_default(svo_config* c) {
 
 // cv::buildOpticalFlowPyramid's level rule: level 0 always, stop as soon as
 // the NEXT level would have width <= win or height <= win.
-static void make_geometry(Geometry& g, int W, int H, int win, int max_level) {
+static void make_geometry(Geometry& g, int W, int H, int win, int max_level, int pad) {
     memset(&g, 0, sizeof(g));
-    g.W = W; g.H = H;
+    g.W = W; g.H = H; g.pad = pad;
     if (max_level > SVO_MAX_LEVELS - 1) max_level = SVO_MAX_LEVELS - 1;
-    int w = W, h = H, off = 0;
+    int w = W, h = H, base = 0;
     for (int l = 0; l <= max_level; l++) {
-        g.lv[l].w = w; g.lv[l].h = h; g.lv[l].off = off;
-        off += (w * h + 15) & ~15;
+        const int stride = (w + 2 * pad + 15) & ~15;
+        g.lv[l].w = w; g.lv[l].h = h; g.lv[l].stride = stride; g.lv[l].off = base + pad * stride + pad;
+        base += stride * (h + 2 * pad);
         g.nlevels = l + 1;
         w = (w + 1) / 2; h = (h + 1) / 2;
         if (w <= win || h <= win) break;
     }
-    g.pyr_bytes = off;
+    g.pyr_bytes = base;
 }
 
 struct svo_context {
@@ -143,7 +144,7 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     if (d.CAP < 64) d.CAP = 64;
     if (cap_override > d.CAP) d.CAP = cap_override;
     c->lk_grid = (cfg.max_features > 0 && cfg.max_features < d.CAP) ? cfg.max_features : d.CAP;
-    make_geometry(d.geom, width, height, cfg.win_w, cfg.max_level);
+    make_geometry(d.geom, width, height, cfg.win_w, cfg.max_level, lk_pad_for(cfg.win_w));
     d.lk_mineig_cut = lk_mineig_cut(cfg.win_w, cfg.optical_flow_min_eig_threshold);
     {
         double pc = (double)cfg.ransac_confidence; pc = pc > 0. ? pc : 0.; pc = pc < 1. ? pc : 1.;
@@ -746,8 +747,9 @@ static int upload_image(svo_context* c, int slot, int cam, const uint8_t* img, i
     uint8_t* h = c->h_upload + W * H * (size_t)(slot * 2 + cam);
     if ((size_t)stride == W) memcpy(h, img, W * H);
     else for (size_t y = 0; y < H; y++) memcpy(h + y * W, img + y * (size_t)stride, W);
-    uint8_t* dst = c->d.pyr + pyr_index(c->d, 0, slot, cam);
-    HIPCHK(hipMemcpyAsync(dst, h, W * H, hipMemcpyHostToDevice, c->stream));
+    const LevelInfo& L0 = c->d.geom.lv[0];
+    uint8_t* dst = c->d.pyr + pyr_index(c->d, 0, slot, cam) + L0.off;
+    HIPCHK(hipMemcpy2DAsync(dst, (size_t)L0.stride, h, W, W, H, hipMemcpyHostToDevice, c->stream));   // from pinned memory: one strided DMA
     return SVO_OK;
 }
 static int set_state(svo_context* c, const SeqState& hs) {
@@ -861,9 +863,10 @@ extern "C" int svo_build_pyramid(int device, const uint8_t* img, int w, int h, i
     cfg.win_w = cfg.win_h = lk_window_supported(win) ? win : 10; cfg.max_level = max_level;
     CtxGuard g; int rc = ctx_create(&cfg, device, 1, w, h, 0, &g.c); if (rc != SVO_OK) return rc;
     svo_context* c = g.c;
-    make_geometry(c->d.geom, w, h, win, max_level);       // honour the caller's window for the level-stop rule
+    const int pad = c->d.geom.pad;
+    make_geometry(c->d.geom, w, h, win, max_level, pad);  // honour the caller's window for the level-stop rule
     // (pyramid buffers were sized with a window >= 7, which never yields fewer bytes than a larger window)
-    Geometry chk; make_geometry(chk, w, h, cfg.win_w, max_level);
+    Geometry chk; make_geometry(chk, w, h, cfg.win_w, max_level, pad);
     if (c->d.geom.pyr_bytes > chk.pyr_bytes) return fail_arg("window too small for this entry point");
     rc = upload_image(c, 0, 0, img, stride); if (rc != SVO_OK) return rc;
     SeqState hs; memset(&hs, 0, sizeof(hs));
@@ -875,7 +878,7 @@ extern "C" int svo_build_pyramid(int device, const uint8_t* img, int w, int h, i
         const LevelInfo& L = c->d.geom.lv[l];
         int64_t sz = (int64_t)L.w * L.h;
         if (off + sz > levels_cap) return fail_arg("levels_out too small");
-        HIPCHK(hipMemcpy(levels_out + off, c->d.pyr + pyr_index(c->d, 0, 0, 0) + L.off, (size_t)sz, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy2D(levels_out + off, (size_t)L.w, c->d.pyr + pyr_index(c->d, 0, 0, 0) + L.off, (size_t)L.stride, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
         off += sz;
     }
     *n_levels_out = c->d.geom.nlevels;

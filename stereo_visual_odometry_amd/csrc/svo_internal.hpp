@@ -10,12 +10,17 @@
 #define SVO_RING 8            // results ring / max frames in flight
 #define SVO_MAX_WIN 31
 
-struct LevelInfo { int w, h, off; };          // off: byte offset of the level inside one pyramid buffer
+// A pyramid level is stored WITH its REFLECT_101 border, as cv::buildOpticalFlowPyramid stores it (withDerivatives = false,
+// pyrBorder = BORDER_REFLECT_101): `pad` pixels on every side, rows `stride` bytes apart.  The LK kernel then reads every window
+// it may visit (origin in [-win, size), lkpyramid.cpp) with plain loads — no per-byte border arithmetic in its loops.
+// off: byte offset of pixel (0, 0) of the level inside one pyramid buffer.
+struct LevelInfo { int w, h, off, stride; };
 struct Geometry {
     int W, H;
     int nlevels;                              // levels actually built (cv::buildOpticalFlowPyramid stop rule)
+    int pad;                                  // border pixels on every side of every level (lk_pad_for(win): covers the widest read of the LK kernel)
     LevelInfo lv[SVO_MAX_LEVELS];
-    int pyr_bytes;                            // bytes of one pyramid (all levels, tightly packed, 16-B aligned levels)
+    int pyr_bytes;                            // bytes of one pyramid (all levels with their borders; strides are multiples of 16)
 };
 
 // Device-resident state of one sequence = the members of the reference's VisualOdometry (include/vo.h:233-269).
@@ -104,7 +109,9 @@ __host__ __device__ inline int pnp_first_chunk(const DevBuffers& d) { const int 
 // ---- launchers (each enqueues on `s`; none synchronises) ----
 void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs /* [2][B] device-readable array */, int stride_bytes, hipStream_t s,
                    bool begin_frame /* also run the per-frame reset of stereo_callback */);
-void launch_pyramid(const DevBuffers& d, hipStream_t s);
+void launch_pyramid(const DevBuffers& d, hipStream_t s);                 // levels 1.. of the T1 slot from its level 0, then the borders of all levels
+void launch_pad_pyramid(const DevBuffers& d, hipStream_t s);             // REFLECT_101 borders of every level of the T1 slot (both cameras, every plane)
+int lk_pad_for(int win);                                                 // border width the LK kernel's reads need at this window (svo_kernels_lk.hip)
 void launch_ingest_pyramid(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride_bytes, hipStream_t s, bool begin_frame);   // both, fewer launches
 void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s);   // pass 0: FAST_THRESHOLD, pass 1: /4 if needed; th_override >= 0 replaces it
 // grid_n = max features that can enter LK; early_out: a feature stops at its first pass with status 0 (frame pipeline) or runs all four (member call)

@@ -71,11 +71,12 @@ __global__ __launch_bounds__(256) void k_ingest(DevBuffers d, const uint8_t* con
     const uint8_t* src = srcs[cam * d.B + seq];
     const int slot = begin_frame ? free_slot(d.st[seq]) : d.st[seq].slot_t1;
     if (begin_frame && blockIdx.x == 0 && cam == 0 && threadIdx.x == 0) frame_begin(d.st[seq]);
-    uint8_t* dst = d.pyr + pyr_index(d, seq, slot, cam);
+    uint8_t* dst = d.pyr + pyr_index(d, seq, slot, cam) + d.geom.lv[0].off;
+    const int dstride = d.geom.lv[0].stride;
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
         int y = q / quads_per_row, x = (q - y * quads_per_row) << 2;
         const uint8_t* sp = src + (size_t)y * stride + x;
-        uint8_t* dp = dst + (size_t)y * W + x;
+        uint8_t* dp = dst + (size_t)y * dstride + x;
         int n = W - x < 4 ? W - x : 4;
         for (int k = 0; k < n; k++) dp[k] = sp[k];
     }
@@ -90,13 +91,15 @@ __global__ __launch_bounds__(256) void k_ingest_bgr(DevBuffers d, const uint8_t*
     const uint8_t* src = srcs[cam * d.B + seq];
     const int slot = begin_frame ? free_slot(d.st[seq]) : d.st[seq].slot_t1;
     if (begin_frame && blockIdx.x == 0 && cam == 0 && threadIdx.x == 0) frame_begin(d.st[seq]);
-    uint8_t* p0 = d.pyr + pyr_index(d, seq, slot, cam);
+    uint8_t* p0 = d.pyr + pyr_index(d, seq, slot, cam) + d.geom.lv[0].off;
+    const int dstride = d.geom.lv[0].stride;
     uint8_t* fi = d.fastimg + fastimg_index(d, seq, slot);
     const size_t pb = (size_t)d.geom.pyr_bytes;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int y = i / W, x = i - y * W;
         const uint8_t* sp = src + (size_t)y * stride;
-        p0[i] = sp[3 * x]; p0[pb + i] = sp[3 * x + 1]; p0[2 * pb + i] = sp[3 * x + 2];
+        const size_t o = (size_t)y * dstride + x;
+        p0[o] = sp[3 * x]; p0[pb + o] = sp[3 * x + 1]; p0[2 * pb + o] = sp[3 * x + 2];
         if (cam == 0) fi[i] = sp[x];
     }
 }
@@ -139,13 +142,13 @@ __global__ __launch_bounds__(256) void k_pyrdown(DevBuffers d, int level) {
         constexpr int DPR = (SW + 1) / 4;
         for (int i = threadIdx.x; i < DPR * SH; i += 256) {
             int ty = i / DPR, c = i - ty * DPR;
-            const unsigned v = reinterpret_cast<const UD*>(src + (size_t)(sy0 + ty) * ls.w + sx0 + 4 * c)->v;
+            const unsigned v = reinterpret_cast<const UD*>(src + (size_t)(sy0 + ty) * ls.stride + sx0 + 4 * c)->v;
             *reinterpret_cast<unsigned*>(&tile[ty][4 * c]) = v;
         }
     } else {
         for (int i = threadIdx.x; i < SW * SH; i += 256) {
             int ty = i / SW, tx = i - ty * SW;
-            tile[ty][tx] = src[(size_t)reflect101(sy0 + ty, ls.h) * ls.w + reflect101(sx0 + tx, ls.w)];
+            tile[ty][tx] = src[(size_t)reflect101(sy0 + ty, ls.h) * ls.stride + reflect101(sx0 + tx, ls.w)];
         }
     }
     __syncthreads();
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void k_pyrdown(DevBuffers d, int level) {
         int gx = ox + x, gy = oy + y;
         if (gx < ld.w && gy < ld.h) {
             int v = hrow[2 * y + 2][x] * 6 + (hrow[2 * y + 1][x] + hrow[2 * y + 3][x]) * 4 + hrow[2 * y][x] + hrow[2 * y + 4][x];
-            dst[(size_t)gy * ld.w + gx] = (uint8_t)((v + 128) >> 8);
+            dst[(size_t)gy * ld.stride + gx] = (uint8_t)((v + 128) >> 8);
         }
     }
 }
@@ -194,7 +197,7 @@ static __device__ __forceinline__ void ingest_pyr1_body(const DevBuffers& d, con
         {   // the block's own 64 x 16 level-0 pixels: one dword per thread
             const int ty = threadIdx.x >> 4, c = threadIdx.x & 15;
             UD u; u.v = (unsigned)tile[ty + 2][4 * c + 2] | ((unsigned)tile[ty + 2][4 * c + 3] << 8) | ((unsigned)tile[ty + 2][4 * c + 4] << 16) | ((unsigned)tile[ty + 2][4 * c + 5] << 24);
-            *reinterpret_cast<UD*>(l0 + (size_t)(2 * oy + ty) * ls.w + 2 * ox + 4 * c) = u;
+            *reinterpret_cast<UD*>(l0 + (size_t)(2 * oy + ty) * ls.stride + 2 * ox + 4 * c) = u;
         }
     } else {
         for (int i = threadIdx.x; i < SW * SH; i += 256) {
@@ -205,7 +208,7 @@ static __device__ __forceinline__ void ingest_pyr1_body(const DevBuffers& d, con
         for (int i = threadIdx.x; i < 2 * PD_TW * 2 * PD_TH; i += 256) {
             const int ty = i / (2 * PD_TW), tx = i - ty * (2 * PD_TW);
             const int gx = 2 * ox + tx, gy = 2 * oy + ty;
-            if (gx < ls.w && gy < ls.h) l0[(size_t)gy * ls.w + gx] = tile[ty + 2][tx + 2];   // in range: the tile holds the pixel itself
+            if (gx < ls.w && gy < ls.h) l0[(size_t)gy * ls.stride + gx] = tile[ty + 2][tx + 2];   // in range: the tile holds the pixel itself
         }
     }
     for (int i = threadIdx.x; i < SH * PD_TW; i += 256) {
@@ -219,7 +222,7 @@ static __device__ __forceinline__ void ingest_pyr1_body(const DevBuffers& d, con
         int gx = ox + x, gy = oy + y;
         if (gx < ld.w && gy < ld.h) {
             int v = hrow[2 * y + 2][x] * 6 + (hrow[2 * y + 1][x] + hrow[2 * y + 3][x]) * 4 + hrow[2 * y][x] + hrow[2 * y + 4][x];
-            dst[(size_t)gy * ld.w + gx] = (uint8_t)((v + 128) >> 8);
+            dst[(size_t)gy * ld.stride + gx] = (uint8_t)((v + 128) >> 8);
         }
     }
 }
@@ -251,7 +254,7 @@ static __device__ __forceinline__ void pyrdown2_body(const DevBuffers& d, int le
     const int sx0 = 2 * mx0 - 2, sy0 = 2 * my0 - 2;              // level l
     for (int i = threadIdx.x; i < SW * SH; i += 256) {
         int ty = i / SW, tx = i - ty * SW;
-        tile[ty][tx] = src[(size_t)reflect101(sy0 + ty, ls.h) * ls.w + reflect101(sx0 + tx, ls.w)];
+        tile[ty][tx] = src[(size_t)reflect101(sy0 + ty, ls.h) * ls.stride + reflect101(sx0 + tx, ls.w)];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SH * MW; i += 256) {
@@ -266,7 +269,7 @@ static __device__ __forceinline__ void pyrdown2_body(const DevBuffers& d, int le
         const uint8_t m = (uint8_t)((v + 128) >> 8);
         mtile[y][x] = m;
         const int gx = mx0 + x, gy = my0 + y;
-        if (x >= 2 && x < 2 + 2 * P2_TW && y >= 2 && y < 2 + 2 * P2_TH && gx < lm.w && gy < lm.h) mid[(size_t)gy * lm.w + gx] = m;   // the owned 32 x 16
+        if (x >= 2 && x < 2 + 2 * P2_TW && y >= 2 && y < 2 + 2 * P2_TH && gx < lm.w && gy < lm.h) mid[(size_t)gy * lm.stride + gx] = m;   // the owned 32 x 16
     }
     __syncthreads();
     for (int i = threadIdx.x; i < MH * P2_TW; i += 256) {
@@ -290,11 +293,38 @@ static __device__ __forceinline__ void pyrdown2_body(const DevBuffers& d, int le
         int gx = ox + x, gy = oy + y;
         if (gx < ld.w && gy < ld.h) {
             int v = hrow2[2 * y + 2][x] * 6 + (hrow2[2 * y + 1][x] + hrow2[2 * y + 3][x]) * 4 + hrow2[2 * y][x] + hrow2[2 * y + 4][x];
-            dst[(size_t)gy * ld.w + gx] = (uint8_t)((v + 128) >> 8);
+            dst[(size_t)gy * ld.stride + gx] = (uint8_t)((v + 128) >> 8);
         }
     }
 }
 __global__ __launch_bounds__(256) void k_pyrdown2(DevBuffers d, int level) { pyrdown2_body(d, level, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// k_pad_pyramid: the REFLECT_101 border of every level of the T1 slot — what cv::buildOpticalFlowPyramid's copyMakeBorder leaves
+// around each level (pyrBorder = BORDER_REFLECT_101).  One thread per border pixel: the ring of a level is cut into its top and
+// bottom bands (pad rows of the padded width) and its left and right bands (h rows of pad pixels); pixel (x, y) outside the level
+// takes level(reflect101(y), reflect101(x)) — the same index function the LK kernel's per-byte border path used before the border
+// was materialised, so the values it sees are the same bytes.
+__global__ __launch_bounds__(256) void k_pad_pyramid(DevBuffers d) {
+    const int plane = blockIdx.z % d.CN, sc = blockIdx.z / d.CN;
+    const int seq = sc / 2, cam = sc & 1, level = blockIdx.y;
+    const LevelInfo L = d.geom.lv[level];
+    const int P = d.geom.pad;
+    uint8_t* img = d.pyr + pyr_index(d, seq, d.st[seq].slot_t1, cam) + (size_t)plane * d.geom.pyr_bytes + L.off;
+    const int pw = L.w + 2 * P, band = P * pw, side = L.h * P;
+    const int total = 2 * band + 2 * side;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int x, y;
+        if (i < 2 * band) { const int j = i < band ? i : i - band; y = j / pw; x = j - y * pw - P; y = i < band ? y - P : L.h + y; }
+        else { const int j = i - 2 * band, k = j < side ? j : j - side; y = k / P; x = k - y * P; x = j < side ? x - P : L.w + x; }
+        img[(ptrdiff_t)y * L.stride + x] = img[(size_t)reflect101(y, L.h) * L.stride + reflect101(x, L.w)];
+    }
+}
+void launch_pad_pyramid(const DevBuffers& d, hipStream_t st) {
+    const LevelInfo& L0 = d.geom.lv[0];
+    const int P = d.geom.pad, ring0 = 2 * P * (L0.w + 2 * P) + 2 * P * L0.h;
+    int gx = (ring0 + 4 * 256 - 1) / (4 * 256); if (gx < 1) gx = 1; if (gx > 64) gx = 64;      // ~4 border pixels per thread at level 0
+    hipLaunchKernelGGL(k_pad_pyramid, dim3(gx, d.geom.nlevels, d.B * 2 * d.CN), dim3(256), 0, st, d);
+}
 
 // levels first .. nlevels-1 from level first-1: pairs of levels per launch where two remain
 static void launch_pyramid_from(const DevBuffers& d, int first, hipStream_t st) {
@@ -311,13 +341,14 @@ static void launch_pyramid_from(const DevBuffers& d, int first, hipStream_t st) 
         }
     }
 }
-void launch_pyramid(const DevBuffers& d, hipStream_t st) { launch_pyramid_from(d, 1, st); }
+void launch_pyramid(const DevBuffers& d, hipStream_t st) { launch_pyramid_from(d, 1, st); launch_pad_pyramid(d, st); }
 // ingest + all pyramid levels of the T1 slot (vo.cpp:74-75, 200-201): single-channel contexts fuse the ingest with the first level
 void launch_ingest_pyramid(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride, hipStream_t st, bool begin_frame) {
     if (d.CN == 1 && d.geom.nlevels >= 2) {
         dim3 g((d.geom.lv[1].w + PD_TW - 1) / PD_TW, (d.geom.lv[1].h + PD_TH - 1) / PD_TH, d.B * 2);
         hipLaunchKernelGGL(k_ingest_pyr1, g, dim3(256), 0, st, d, left_right_dev_ptrs, stride, (int)begin_frame);
         launch_pyramid_from(d, 2, st);
+        launch_pad_pyramid(d, st);
         return;
     }
     launch_ingest(d, left_right_dev_ptrs, stride, st, begin_frame);
@@ -421,7 +452,7 @@ static __device__ __forceinline__ void fast_body(const uint8_t* img_single, int 
     __shared__ unsigned short cand[FT_SH * FT_SW];               // screened pixels of the tile (order is irrelevant)
     __shared__ int ncand;
     const int seq = bz;
-    int W, H; const uint8_t* img;
+    int W, H, istride; const uint8_t* img;                       // istride: row pitch of img (a pyramid level 0 carries its border)
     if (MODE != 1) {
         const SeqState& s = d.st[seq];
         // Pass 0 reads nothing the per-frame reset writes (`active` is frame_id > 0, `n_old` is n_feat until the first emit), so
@@ -429,11 +460,12 @@ static __device__ __forceinline__ void fast_body(const uint8_t* img_single, int 
         if (pass == 0 ? !(s.frame_id > 0) : !s.do_second) return;
         W = d.geom.W; H = d.geom.H;
         // FAST runs on the PREVIOUS left image (vo.cpp:325); for a BGR context on the byte image cv::FAST really scans
-        img = d.CN == 3 ? d.fastimg + fastimg_index(d, seq, s.slot_img_t0) : d.pyr + pyr_index(d, seq, s.slot_img_t0, 0);
+        img = d.CN == 3 ? d.fastimg + fastimg_index(d, seq, s.slot_img_t0) : d.pyr + pyr_index(d, seq, s.slot_img_t0, 0) + d.geom.lv[0].off;
+        istride = d.CN == 3 ? W : d.geom.lv[0].stride;
         if (MODE == 2) score_out = d.score + (size_t)seq * W * H;
         if (TO_BUCKETS && pass == 0)                                 // the existing tracks enter the grid here (no launch of their own)
             offer_tracks(d, seq, s.feat_buf, s.n_feat, (by * gdx + bx) * 256 + threadIdx.x, gdx * gdy * 256);
-    } else { W = w_single; H = h_single; img = img_single; }
+    } else { W = w_single; H = h_single; img = img_single; istride = w_single; }
     if (threshold < 0) threshold = 0;
     if (threshold > 255) threshold = 255;
     const int x0 = bx * FT_W, y0 = by * FT_H;
@@ -444,14 +476,14 @@ static __device__ __forceinline__ void fast_body(const uint8_t* img_single, int 
         constexpr int DPR = FT_PW / 4;
         for (int i = threadIdx.x; i < DPR * FT_PH; i += 256) {
             int py = i / DPR, c = i - py * DPR;
-            const unsigned v = reinterpret_cast<const UD*>(img + (size_t)(y0 - 4 + py) * W + (x0 - 4) + 4 * c)->v;
+            const unsigned v = reinterpret_cast<const UD*>(img + (size_t)(y0 - 4 + py) * istride + (x0 - 4) + 4 * c)->v;
             *reinterpret_cast<unsigned*>(&pix[py][4 * c]) = v;
         }
     } else {
         for (int i = threadIdx.x; i < FT_PH * FT_PW; i += 256) {
             int py = i / FT_PW, px = i - py * FT_PW;
             int gx = x0 - 4 + px, gy = y0 - 4 + py;
-            pix[py][px] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(size_t)gy * W + gx] : (uint8_t)0;
+            pix[py][px] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? img[(size_t)gy * istride + gx] : (uint8_t)0;
         }
     }
     if (threadIdx.x == 0) ncand = 0;
@@ -669,6 +701,7 @@ bool launch_front_fused(const DevBuffers& d, const uint8_t* const* left_right_de
     const int n_rows = d.cfg.buckets_along_height;
     hipLaunchKernelGGL(k_front_b, dim3(n_p + n_rows * d.B), dim3(256), 0, st, d, px, py, n_p, n_rows);
     launch_pyramid_from(d, 4, st);                                    // a fifth level and beyond (cfg3)
+    launch_pad_pyramid(d, st);
     launch_detect(d, 1, -1, st);                                      // the second pass exits at once unless needed (vo.cpp:327-332)
     return true;
 }

@@ -55,6 +55,17 @@ template <int W, int G> struct LkLayout {
     static constexpr int NB = PPL + 1;                // search-window bytes per segment per row
 };
 
+// Border width the kernel's reads need around every pyramid level at window `win` (Geometry::pad): the template reads rows and
+// columns origin - 1 .. origin + EXT + 1 (+ up to 3 bytes of the last dword) with origin in [-win, size), the search window
+// origin .. origin + EXT.  Same PPL / EXT recipe as LkLayout (which does not depend on the lanes per feature).
+int lk_pad_for(int win) {
+    if (win < 1) win = 1;
+    int ppl = win;
+    for (int p = 1; p <= win; p++) if (win * ((win + p - 1) / p) <= 64) { ppl = p; break; }
+    const int ext = ((win + ppl - 1) / ppl) * ppl;
+    return (ext + 5 + 3) & ~3;
+}
+
 // one doubling step of the in-row DPP reduction (S = 0..3: lane pairs, quads, half rows, rows)
 template <int S>
 __device__ __forceinline__ int dpp_row_step(int v) {
@@ -413,32 +424,19 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         // 1 <= ipx && ipx + EXT + 1 < w  <=>  (unsigned)(ipx - 1) < (unsigned)(w - EXT - 2)   (a non-positive bound never holds: the image is larger than the window)
         const bool interior = uni<G>(ipx >= 1 && ipx + EXT + 1 < L.w && ipy >= 1 && ipy + W + 1 < L.h);
         // interior windows: one (wave-uniform for G == 64) base address per level visit, 32-bit lane offsets
-        const uint8_t* __restrict__ Abase = A + (size_t)(uni_i<G>(ipy) - 1) * L.w + (uni_i<G>(ipx) - 1);
+        const uint8_t* __restrict__ Abase = A + (ptrdiff_t)(uni_i<G>(ipy) - 1) * L.stride + (uni_i<G>(ipx) - 1);
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) {
             const int k = kk % SPL;
-            const uint8_t* __restrict__ Ap = A + (size_t)(kk / SPL) * pstride;       // this colour plane
             const int row = sg.row[k], xs = sg.xs[k];
             unsigned Ip[2][PPL], DXp[2][PPL], DYp[2][PPL];             // [row 0/1 of the bilinear][pixel]: packed pairs
-            // source pairs of the four rows: interior windows take unaligned dword loads; windows over the image border gather
-            // their bytes through REFLECT_101 (the border of the pyramid level) — everything after that is shared
+            // source pairs of the four rows: unaligned dword loads.  A window over the image border reads the level's REFLECT_101
+            // border, which is stored with it (Geometry::pad, k_pad_pyramid) — the same bytes the per-byte path used to gather
             unsigned Q[4][NS - 1];
-            if (interior) {
-                const uint8_t* p = Abase + (size_t)(kk / SPL) * pstride + (unsigned)(row * L.w + xs);
+            {
+                const uint8_t* p = Abase + (size_t)(kk / SPL) * pstride + (unsigned)(row * L.stride + xs);
 #pragma unroll
-                for (int r = 0; r < 4; r++) load_pairs<NS>(p + (unsigned)(r * L.w), Q[r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint8_t* rp = Ap + (size_t)reflect101(ipy - 1 + row + r, L.h) * L.w;
-                    int prev = rp[reflect101(ipx - 1 + xs, L.w)];
-#pragma unroll
-                    for (int c = 0; c < NS - 1; c++) {
-                        const int nxt = rp[reflect101(ipx + xs + c, L.w)];
-                        Q[r][c] = pack16(prev, nxt);
-                        prev = nxt;
-                    }
-                }
+                for (int r = 0; r < 4; r++) load_pairs<NS>(p + (unsigned)(r * L.stride), Q[r]);
             }
 #pragma unroll
             for (int yy = 0; yy < 2; yy++) {
@@ -560,31 +558,14 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         bool moved = false, osc = false;
         unsigned P0[KS][PPL], P1[KS][PPL];
         auto load_window = [&](int inx, int iny) __attribute__((always_inline)) {
-            if (uni<G>(inx >= 0 && inx + EXT < L.w && iny >= 0 && iny + W < L.h)) {
-                const uint8_t* base = Bm + (size_t)uni_i<G>(iny) * L.w + uni_i<G>(inx);
+            // any origin in reach ([-W, size) per axis) lies inside the stored border
+            const uint8_t* base = Bm + (ptrdiff_t)uni_i<G>(iny) * L.stride + uni_i<G>(inx);
 #pragma unroll
-                for (int kk = 0; kk < KS; kk++) {
-                    const int k = kk % SPL;
-                    const uint8_t* p = base + (size_t)(kk / SPL) * pstride + (unsigned)(sg.row[k] * L.w + sg.xs[k]);
-                    load_pairs<NB>(p, P0[kk]);
-                    load_pairs<NB>(p + L.w, P1[kk]);
-                }
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < KS; kk++) {
-                    const int k = kk % SPL;
-#pragma unroll
-                    for (int r = 0; r < 2; r++) {
-                        const uint8_t* rp = Bm + (size_t)(kk / SPL) * pstride + (size_t)reflect101(iny + sg.row[k] + r, L.h) * L.w;
-                        int prev = rp[reflect101(inx + sg.xs[k], L.w)];
-#pragma unroll
-                        for (int c = 0; c < PPL; c++) {
-                            const int nxt = rp[reflect101(inx + sg.xs[k] + c + 1, L.w)];
-                            (r ? P1 : P0)[kk][c] = pack16(prev, nxt);
-                            prev = nxt;
-                        }
-                    }
-                }
+            for (int kk = 0; kk < KS; kk++) {
+                const int k = kk % SPL;
+                const uint8_t* p = base + (size_t)(kk / SPL) * pstride + (unsigned)(sg.row[k] * L.stride + sg.xs[k]);
+                load_pairs<NB>(p, P0[kk]);
+                load_pairs<NB>(p + L.stride, P1[kk]);
             }
         };
         // one Newton step with the window loaded at the integer origin the fractions (fa, fb) = n - origin refer to;
