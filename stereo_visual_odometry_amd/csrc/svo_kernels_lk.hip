@@ -554,8 +554,9 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         // re-loaded only when the INTEGER window origin floor(n) changes; most iterations move the window by a fraction of
         // a pixel and touch no memory.
         int j = 0;
+        const int max_count = uni_i<G>(crit.max_count);
         float pdx = 0.f, pdy = 0.f, ldx = 0.f, ldy = 0.f;
-        bool moved = false, osc = false;
+        bool moved = false, osc = false, conv = false;
         unsigned P0[KS][PPL], P1[KS][PPL];
         auto load_window = [&](int inx, int iny) __attribute__((always_inline)) {
             // any origin in reach ([-W, size) per axis) lies inside the stored border
@@ -572,7 +573,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
         // returns true when the track is finished at this level
         auto newton_step = [&](float fa, float fb) __attribute__((always_inline)) -> bool {
             lk_weights(fa, fb, w0, w1);
-            n_steps++;
+            if constexpr (G != 64) n_steps++;                               // one feature per wave: counted from j after the loop (scalar)
             int pb1 = 0, pb2 = 0;
 #pragma unroll
             for (int kk = 0; kk < KS; kk++) {
@@ -636,8 +637,8 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
             // (relative) of the exact one, so away from the threshold it decides; the f64 form only runs in the gap.
             const float s32 = dx * dx + dy * dy;
             if (!uni<G>(s32 > crit.eps_hi)) {
-                if (uni<G>(s32 < crit.eps_lo)) return true;
-                if (uni<G>((double)dx * (double)dx + (double)dy * (double)dy <= crit.eps2)) return true;
+                if (uni<G>(s32 < crit.eps_lo)) { conv = true; return true; }
+                if (uni<G>((double)dx * (double)dx + (double)dy * (double)dy <= crit.eps2)) { conv = true; return true; }
             }
             // "(double)|v| < 0.01" for a float v is exactly "|v| < nextafterf((float)0.01)": 0.01 lies between the floats
             // 0x3C23D70A and 0x3C23D70B, so v < 0.01 (as doubles) <=> v <= 0x3C23D70A <=> v < 0x3C23D70B
@@ -646,20 +647,21 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 return true;
             }
             pdx = dx; pdy = dy;
-            return ++j >= crit.max_count;
+            return ++j >= max_count;
         };
         if (LK_LOOP_FORM(G) == 0) {
             // one or two features per wave: epochs of constant integer origin, the inner loop is pure register arithmetic
             // (measured on MI355X, LK chain ms for 32 sequences, epoch / flat: W=21 G=64 2.12 / 2.42, W=15 G=32 1.48 / 1.55)
-            bool stop = crit.max_count <= 0;
+            bool stop = max_count <= 0;
             while (!stop) {
-                const int inx = (int)floorf(nx), iny = (int)floorf(ny);
-                if (uni<G>(inx < -W || inx >= L.w || iny < -W || iny >= L.h)) {
+                const float fx0 = floorf(nx), fy0 = floorf(ny);             // (float)(int)floorf(n) == floorf(n) wherever the origin is in reach
+                const int inx = (int)fx0, iny = (int)fy0;
+                // -W <= in < size  <=>  (unsigned)(in + W) < (unsigned)(size + W): one compare per axis
+                if (uni<G>((unsigned)(inx + W) >= (unsigned)(L.w + W) || (unsigned)(iny + W) >= (unsigned)(L.h + W))) {
                     if (level == 0) status = 0;
                     break;
                 }
                 load_window(inx, iny);
-                const float fx0 = (float)inx, fy0 = (float)iny;
                 float fa = nx - fx0, fb = ny - fy0;
                 for (;;) {
                     if (newton_step(fa, fb)) { stop = true; break; }
@@ -690,6 +692,7 @@ __device__ void lk_pass(const Geometry& g, const uint8_t* __restrict__ pyrA, con
                 if (newton_step(nx - (float)inx, ny - (float)iny)) break;
             }
         }
+        if constexpr (G == 64) n_steps += j + ((conv || osc) ? 1 : 0);       // a step that ends the track returns before ++j
         if (moved) {                                                         // nextPts[i] = nextPt + halfWin (every iteration in lkpyramid.cpp)
             outx = nx + half; outy = ny + half;
             if (osc) { outx -= ldx * 0.5f; outy -= ldy * 0.5f; }
@@ -749,11 +752,74 @@ __device__ __forceinline__ LkCrit make_crit(const svo_config& c, float mineig_cu
 #define LK_MAP_STRIPE 0
 #define LK_MAP_AFFINE 1
 #define LK_MAP_INTERLEAVED 2
-// Register budget: left to the compiler (w = 21: 104 VGPRs, four waves per SIMD).  Asking for a fifth wave (91 VGPRs, no
-// scratch) or for a third at w = 31 was measured on one box against this build and is not faster — 1 % slower at the
-// default two-context configuration, where the other kernels' waves have to fit beside LK's; a sixth wave spills.
+// The four passes of ONE feature (or FPW features side by side) and its masks: one inlined copy inside k_lk_chain (experiments/lk_queue_fed_persistent.patch fed the same function from a work queue).
+struct LkSeqCtx { const uint8_t *L0, *R0, *L1, *R1; int seq, buf; };
+template <int W, int G, int CN, bool FS>
+__device__ __forceinline__ void lk_chain_feature(const DevBuffers& d, const LkSeqCtx& q, int idx, const LkCrit& crit, float thr, float Wf, float Hf,
+                                                 const LkSegs<LkLayout<W, G>::SPL>& sg, int early_out, int* fs_lds) {
+    constexpr int FPW = 64 / G;
+    const int seq = q.seq;
+    const uint8_t *L0 = q.L0, *R0 = q.R0, *L1 = q.L1, *R1 = q.R1;
+    const size_t o = (size_t)seq * d.CAP + idx;
+    const float2 p0 = d.feat_xy[q.buf][o];                  // pointsLeftT0 = currentVOFeatures.points (vo.cpp:338)
+    // the four passes share ONE inlined copy of lk_pass (a loop, not four copies): 4x less code in the instruction cache.
+    // Every pass's point is written out and folded into the masks as soon as it exists, so only the running point,
+    // the start point and two flags stay live across the passes (fewer registers held through lk_pass).
+    const bool writer = threadIdx.x % G == 0;
+    // per-feature state across the passes, packed so that it holds ONE register through lk_pass (the kernel sits at the edge
+    // of its register budget: 104 VGPRs leave room for the other context's f64 kernels, svo_api.hip LkGate): bit 0 = every
+    // status so far is 1, bit 1 = every point so far lies inside the image, bits 2-3 = 1 + the first pass (0..2) that
+    // returned status 0 (0 = none)
+    int flags = 1 | ((!((p0.x < 0) || (p0.y < 0) || (p0.y >= Hf) || (p0.x >= Wf))) << 1);         // vo.cpp:344-359, pointsLeftT0
+    float2 cur = p0;
+    int n_visits = 0, n_steps = 0;                                 // svo_frame_stats.lk_level_visits / lk_newton_steps
+    if (writer) d.pl0[o] = p0;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; pass++) {
+        const uint8_t* A = pass == 0 ? L0 : pass == 1 ? L1 : pass == 2 ? R1 : R0;      // vo.cpp:203, 206, 209, 213
+        const uint8_t* Bq = pass == 0 ? L1 : pass == 1 ? R1 : pass == 2 ? R0 : L0;
+        float2* out = pass == 0 ? d.pl1 : pass == 1 ? d.pr1 : pass == 2 ? d.pr0 : d.plc;
+        float2 q; int st;
+        lk_pass<W, G, CN, FS>(d.geom, A, Bq, (size_t)d.geom.pyr_bytes, cur.x, cur.y, q.x, q.y, st, crit, sg, n_visits, n_steps, fs_lds);
+        if (pass < 3 && ((q.x < 0) || (q.y < 0) || (q.y >= Hf) || (q.x >= Wf))) flags &= ~2;     // pl1, pr1, pr0 (not the returned point)
+        if (writer) out[o] = q;
+        cur = q;
+        // A feature whose status is 0 is deleted at vo.cpp:233-238 whatever the remaining passes return (the mask is the AND of
+        // the four statuses, vo.cpp:227-230): the frame pipeline stops here — nothing it reports can tell.  The member-call form
+        // (svo_circular_matching) hands the raw points of every pass to the caller and runs all four (early_out = 0).
+        if (st == 0) {
+            if ((flags & 1) && pass < 3) flags |= (pass + 1) << 2;
+            flags &= ~1;
+            if (early_out && pass < 3) { if constexpr (G == 64) { if (uni<G>(true)) break; } else if (FPW == 1) break; }
+        }
+    }
+    if (writer) {
+        float ex = fabsf(p0.x - cur.x), ey = fabsf(p0.y - cur.y);
+        float off = (ex < ey) ? ey : ex;
+        int circ = (flags & 1) && !(off > thr);                                         // vo.cpp:227-230
+        d.okmask[o] = (uint8_t)(circ | (flags & 2));
+        // work counters of svo_frame_stats: one plain store per feature, summed by k_compact (two atomicAdd per feature on
+        // one address per sequence kept every wave's slot occupied until they drained: +14 % LK time, measured)
+        d.lk_work[o] = ((unsigned)n_steps << 8) | ((unsigned)(flags >> 2) << 6) | (unsigned)n_visits;
+    }
+
+}
+
+// Waves per SIMD asked of the compiler (its register budget is 512 / waves, allocated in eights).  Since the pyramid levels carry
+// their border the kernel needs 82 registers at w = 21 (99 with the per-byte border paths) and is no longer purely issue-bound —
+// a wave waits for ~40 dependent loads per feature — so more resident waves pay: measured on one box (tools/ab_bench.sh, LK ms per
+// 32-sequence launch / whole job at the default two-context configuration): 5 waves (82 registers, the compiler's own choice)
+// 1.76 / 17 240, 6 waves (80, 2 dwords of scratch) 1.72 / 17 650, 7 waves (72, 10 dwords of scratch) 1.72 / 17 820.  Other windows
+// keep the compiler's choice (not measured).  Beside 7 x 72 registers nothing of the other context fits, so the LkGate chaining
+// (svo_api.hip) switches itself off and the two contexts' LK grids overlap instead — each fills the other's tail.
+template <int W, int G, int CN, bool FS> constexpr int lk_min_waves() { return (W == 21 && G == 64 && CN == 1 && !FS) ? 7 : 1; }
+#ifdef LK_EXP_MINWAVES                      // experiments: -DLK_EXP_MINWAVES=<n> overrides the table
+#define LK_MIN_WAVES(W, G, CN, FS) LK_EXP_MINWAVES
+#else
+#define LK_MIN_WAVES(W, G, CN, FS) (lk_min_waves<W, G, CN, FS>())
+#endif
 template <int W, int G, int CN, bool FS = false>
-__global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mode, int chunk, int early_out) {
+__global__ __attribute__((amdgpu_flat_work_group_size(1, 64), amdgpu_waves_per_eu(LK_MIN_WAVES(W, G, CN, FS)))) void k_lk_chain(DevBuffers d, int slots, int mode, int chunk, int early_out) {
     constexpr int FPW = 64 / G;                                       // features per wave (= per block)
     __shared__ int fs_lds[FS ? LkFs<W, CN>::LDS_INTS : 1];            // float-sums mode only (the default build uses no LDS)
     int seq, fb;
@@ -775,6 +841,7 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mo
     const uint8_t* R0 = d.pyr + pyr_index(d, seq, s.slot_pyr_t0, 1);
     const uint8_t* L1 = d.pyr + pyr_index(d, seq, s.slot_t1, 0);
     const uint8_t* R1 = d.pyr + pyr_index(d, seq, s.slot_t1, 1);
+    const LkSeqCtx sc = {L0, R0, L1, R1, seq, s.feat_buf};
     const LkCrit crit = make_crit(d.cfg, d.lk_mineig_cut);
     const float thr = (float)d.cfg.circular_matching_success_threshold;                // findClosePoints takes a float32 (vo.h:432)
     const float Wf = (float)d.geom.W, Hf = (float)d.geom.H;
@@ -797,48 +864,7 @@ __global__ __launch_bounds__(64) void k_lk_chain(DevBuffers d, int slots, int mo
         }
         const int idx = grp * FPW + slot;
         if (idx >= n) continue;                                       // whole group idle (group-uniform)
-        const size_t o = (size_t)seq * d.CAP + idx;
-        const float2 p0 = d.feat_xy[s.feat_buf][o];                  // pointsLeftT0 = currentVOFeatures.points (vo.cpp:338)
-        // the four passes share ONE inlined copy of lk_pass (a loop, not four copies): 4x less code in the instruction cache.
-        // Every pass's point is written out and folded into the masks as soon as it exists, so only the running point,
-        // the start point and two flags stay live across the passes (fewer registers held through lk_pass).
-        const bool writer = threadIdx.x % G == 0;
-        // per-feature state across the passes, packed so that it holds ONE register through lk_pass (the kernel sits at the edge
-        // of its register budget: 104 VGPRs leave room for the other context's f64 kernels, svo_api.hip LkGate): bit 0 = every
-        // status so far is 1, bit 1 = every point so far lies inside the image, bits 2-3 = 1 + the first pass (0..2) that
-        // returned status 0 (0 = none)
-        int flags = 1 | ((!((p0.x < 0) || (p0.y < 0) || (p0.y >= Hf) || (p0.x >= Wf))) << 1);         // vo.cpp:344-359, pointsLeftT0
-        float2 cur = p0;
-        int n_visits = 0, n_steps = 0;                                 // svo_frame_stats.lk_level_visits / lk_newton_steps
-        if (writer) d.pl0[o] = p0;
-#pragma unroll 1
-        for (int pass = 0; pass < 4; pass++) {
-            const uint8_t* A = pass == 0 ? L0 : pass == 1 ? L1 : pass == 2 ? R1 : R0;      // vo.cpp:203, 206, 209, 213
-            const uint8_t* Bq = pass == 0 ? L1 : pass == 1 ? R1 : pass == 2 ? R0 : L0;
-            float2* out = pass == 0 ? d.pl1 : pass == 1 ? d.pr1 : pass == 2 ? d.pr0 : d.plc;
-            float2 q; int st;
-            lk_pass<W, G, CN, FS>(d.geom, A, Bq, (size_t)d.geom.pyr_bytes, cur.x, cur.y, q.x, q.y, st, crit, sg, n_visits, n_steps, fs_lds);
-            if (pass < 3 && ((q.x < 0) || (q.y < 0) || (q.y >= Hf) || (q.x >= Wf))) flags &= ~2;     // pl1, pr1, pr0 (not the returned point)
-            if (writer) out[o] = q;
-            cur = q;
-            // A feature whose status is 0 is deleted at vo.cpp:233-238 whatever the remaining passes return (the mask is the AND of
-            // the four statuses, vo.cpp:227-230): the frame pipeline stops here — nothing it reports can tell.  The member-call form
-            // (svo_circular_matching) hands the raw points of every pass to the caller and runs all four (early_out = 0).
-            if (st == 0) {
-                if ((flags & 1) && pass < 3) flags |= (pass + 1) << 2;
-                flags &= ~1;
-                if (early_out && pass < 3) { if constexpr (G == 64) { if (uni<G>(true)) break; } else if (FPW == 1) break; }
-            }
-        }
-        if (writer) {
-            float ex = fabsf(p0.x - cur.x), ey = fabsf(p0.y - cur.y);
-            float off = (ex < ey) ? ey : ex;
-            int circ = (flags & 1) && !(off > thr);                                         // vo.cpp:227-230
-            d.okmask[o] = (uint8_t)(circ | (flags & 2));
-            // work counters of svo_frame_stats: one plain store per feature, summed by k_compact (two atomicAdd per feature on
-            // one address per sequence kept every wave's slot occupied until they drained: +14 % LK time, measured)
-            d.lk_work[o] = ((unsigned)n_steps << 8) | ((unsigned)(flags >> 2) << 6) | (unsigned)n_visits;
-        }
+        lk_chain_feature<W, G, CN, FS>(d, sc, idx, crit, thr, Wf, Hf, sg, early_out, fs_lds);
     }
 }
 
