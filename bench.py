@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--seqs", type=int, default=256, help="independent stereo sequences batched per GPU")
+    ap.add_argument("--seqs", type=int, default=512, help="independent stereo sequences batched per GPU (two contexts of 256: the per-frame chain of small kernels between two LK launches is latency-bound and costs the same for 128 or 256 sequences, so larger batches dilute it — 256 / 512 / 1024 sequences per GPU: 17.8k / 18.2k / 18.3k frame-pairs/s)")
     ap.add_argument("--depth", type=int, default=4, help="frames kept in flight per context (<= 8)")
     ap.add_argument("--contexts", type=int, default=2, help="sequence groups per GPU, each on its own HIP stream (their kernels overlap)")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic sequences rendered per rank (own seed each)")

@@ -806,13 +806,16 @@ __device__ __forceinline__ void lk_chain_feature(const DevBuffers& d, const LkSe
 }
 
 // Waves per SIMD asked of the compiler (its register budget is 512 / waves, allocated in eights).  Since the pyramid levels carry
-// their border the kernel needs 82 registers at w = 21 (99 with the per-byte border paths) and is no longer purely issue-bound —
-// a wave waits for ~40 dependent loads per feature — so more resident waves pay: measured on one box (tools/ab_bench.sh, LK ms per
-// 32-sequence launch / whole job at the default two-context configuration): 5 waves (82 registers, the compiler's own choice)
-// 1.76 / 17 240, 6 waves (80, 2 dwords of scratch) 1.72 / 17 650, 7 waves (72, 10 dwords of scratch) 1.72 / 17 820.  Other windows
-// keep the compiler's choice (not measured).  Beside 7 x 72 registers nothing of the other context fits, so the LkGate chaining
-// (svo_api.hip) switches itself off and the two contexts' LK grids overlap instead — each fills the other's tail.
-template <int W, int G, int CN, bool FS> constexpr int lk_min_waves() { return (W == 21 && G == 64 && CN == 1 && !FS) ? 7 : 1; }
+// their border the kernel needs 82 registers at w = 21 (99 with the per-byte border paths), and more resident waves pay: measured
+// on one box (tools/ab_bench.sh: LK ms per 32-sequence launch / whole job at two contexts of 128 sequences; rocprofv3 FETCH_SIZE +
+// WRITE_SIZE per 32-sequence launch against 163 MB algorithmic):
+//   5 waves (81 registers, the compiler's own choice)   1.76 ms / 17 240 frame-pairs/s / 302 MB
+//   6 waves (80 registers, no scratch)                  1.72 ms / 17 650            / 341 MB
+//   7 waves (72 registers, 10 dwords of scratch)        1.72 ms / 17 820            / 842 MB
+// Six: the seventh wave's 1 % is paid with 0.5 GB of scratch traffic per launch (every single-feature wave spills at entry).  Other
+// windows keep the compiler's choice (not measured).  Beside 6 x 80 registers none of the other context's f64 kernels fits, so the
+// LkGate chaining (svo_api.hip) switches itself off and the two contexts' LK launches follow each other, each filling the other's tail.
+template <int W, int G, int CN, bool FS> constexpr int lk_min_waves() { return (W == 21 && G == 64 && CN == 1 && !FS) ? 6 : 1; }
 #ifdef LK_EXP_MINWAVES                      // experiments: -DLK_EXP_MINWAVES=<n> overrides the table
 #define LK_MIN_WAVES(W, G, CN, FS) LK_EXP_MINWAVES
 #else

@@ -211,17 +211,17 @@ def test_frames_in_page_locked_memory_take_the_copy_free_path_and_give_the_same_
 
 
 def test_lk_kernel_register_budget(api):
-    """The default LK build at the metric's 21x21 window is asked for seven waves per SIMD (lk_min_waves: 72 registers, 7 x 72 =
-    504 of the 512 per SIMD lane): measured faster than five or six.  Fewer than 96 registers then stay free,
-    so the chaining of two contexts' LK launches (LkGate) must be off for it — their grids overlap instead.  A change that costs
-    the seventh wave silently costs the bench ~1 %; one that frees >= 96 registers would switch the chaining back on and change
-    what the bench line's per-launch duration means."""
+    """The default LK build at the metric's 21x21 window is asked for six waves per SIMD (lk_min_waves: 80 registers, no scratch;
+    6 x 80 = 480 of the 512 per SIMD lane): measured against five and seven.  Fewer than 96 registers then
+    stay free, so the chaining of two contexts' LK launches (LkGate) must be off for it.  A change that costs the sixth wave
+    silently costs the bench ~2 %; one that frees >= 96 registers would switch the chaining back on and change what the bench
+    line's per-launch duration means."""
     from stereo_visual_odometry_amd._lib import lib
     lib.svo_get_lk_registers_left.restype = C.c_int
     lib.svo_get_lk_registers_left.argtypes = [C.c_void_p]
     vo = api.BatchVisualOdometry(1241, 376, 1, api.default_config(win_w=21, win_h=21))
     left = lib.svo_get_lk_registers_left(vo._h)
-    assert left in (0, 8), left                                   # 8 waves x 64 or 7 waves x 72
+    assert left == 32, left                                       # 6 waves x 80
     vo.close()
     for win in (10, 31):
         vo = api.BatchVisualOdometry(1241, 376, 1, api.default_config(win_w=win, win_h=win))

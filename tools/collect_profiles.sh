@@ -1,20 +1,21 @@
 # One-call collection of a round's rocprofv3 evidence (MI355X box):  bash tools/collect_profiles.sh r03
 #   -> gpurun_out/<tag>p/ ; then, in the build container:  bash tools/collect_profiles.sh r03 --summarize   copies / reduces into profiles/
-# Kernel stats at 32 / 1 / 256 sequences, the counter passes (FETCH_SIZE, WRITE_SIZE, two SQ passes, GRBM_GUI_ACTIVE — one --pmc
-# pass each, with --kernel-trace only) at the DEFAULT bench configuration (two contexts of 128 sequences: the launch the bench
+# Kernel stats at 32 / 1 / 512 (default) sequences, the counter passes (FETCH_SIZE, WRITE_SIZE, two SQ passes, GRBM_GUI_ACTIVE — one --pmc
+# pass each, with --kernel-trace only) at the DEFAULT bench configuration (two contexts of 256 sequences: the launch the bench
 # line's roofline is about), the bench lines and the latency figures.
 set -e
 TAG=${1:-r03}
 if [ "$2" = "--summarize" ]; then
   O=gpurun_out/${TAG}p
-  python3 profiles/summarize.py ${TAG} $O/s32 $O/fetch $O/write --seqs 128
+  python3 profiles/summarize.py ${TAG} $O/s32 $O/fetch $O/write --seqs 256
   python3 profiles/summarize.py ${TAG} --sq $O/sq1 --bench $O/bench.json --extra $O/sq2 --gui $O/gui
-  cp $(find $O/s256 -name '*kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats_256seq_2ctx.csv
+  cp $(find $O/s256 -name '*kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats_default_2ctx.csv
   cp $(find $O/s1 -name '*kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats_1seq.csv
   cp $(find $O/s1s -name '*kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats_1seq_static.csv
   cp $O/bench.json profiles/${TAG}_bench.json; cp $O/bench_static.json profiles/${TAG}_bench_static.json
-  tail -1 $O/s32.log > profiles/${TAG}_bench_32seq_1ctx.json; tail -1 $O/s256.log > profiles/${TAG}_bench_256seq_under_rocprof.json
+  grep '^{"metric"' $O/s32.log | tail -1 > profiles/${TAG}_bench_32seq_1ctx.json; grep '^{"metric"' $O/s256.log | tail -1 > profiles/${TAG}_bench_default_under_rocprof.json
   cp $O/latency.txt profiles/${TAG}_latency.txt
+  cp $O/latency_cpp.txt profiles/${TAG}_latency_cpp.txt
   exit 0
 fi
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -38,6 +39,9 @@ python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 bench.py --movers 0 --cpu-frames 0 > $O/bench_static.json 2> $O/bench_static.err
 python3 tools/measure_pcie.py > $O/latency.txt 2>&1
 python3 tools/stage_latency.py >> $O/latency.txt 2>&1
+python3 tools/latency_cpp.py 21 300 > $O/latency_cpp.txt 2>/dev/null
+python3 tools/latency_cpp.py 10 300 >> $O/latency_cpp.txt 2>/dev/null
+python3 tools/cfg1_latency.py >> $O/latency_cpp.txt 2>/dev/null
 # keep what travels back small: the per-dispatch traces are large, the summaries and counter CSVs are what profiles/ needs
 find $O -name '*kernel_trace.csv' -size +8M -delete || true
 du -sh $O
