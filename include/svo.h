@@ -138,8 +138,10 @@ int svo_circular_matching(svo_context* ctx, const uint8_t* left_t1, const uint8_
  * (device pointers only; the images must stay valid until the matching svo_collect).
  * Results are queued in order; svo_collect blocks for the oldest outstanding frame. At most 8 in flight. */
 /* Diagnostics: VGPRs one SIMD has left beside a full complement of this context's LK waves (-1 unknown).  Several many-sequence
- * contexts on one device overlap their f64 kernels with each other's LK kernel only when this is >= 96 (w = 21: 100-register
- * LK build, four waves, 96 left); tests pin it so that a change to the LK kernel that costs the overlap fails loudly.
+ * contexts on one device overlap their f64 kernels with each other's LK kernel only when this is >= 96.  At the metric's window
+ * (w = 21, single channel) it is 32 since round 3 — six waves of 80 registers: the faster LK build wins over the overlap, DESIGN.md
+ * section 2 — so such contexts simply take turns; builds that leave >= 96 (w = 31, 3-channel contexts) keep the overlap scheme.  A
+ * test pins the figure, so that a change to the LK kernel that alters the regime fails loudly.
  * NOTE on locality: creating or destroying ANOTHER context with more than 8 sequences on the same device changes which builds of
  * the PnP / triangulation kernels this context launches from its next frame on (full-register alone, 96-register when the
  * device is shared) and whether its LK launches are chained behind the other's.  Results are identical either way. */

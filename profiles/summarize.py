@@ -47,15 +47,18 @@ def sq_summary(tag, sq_dir, bench_json, extra_dirs=(), gui_dir=None, kernel="k_l
            "newton_steps_per_feature": j["roofline"]["valu_flop"]["newton_steps_per_feature"],
            "level_visits_per_feature": j["roofline"]["valu_flop"]["level_visits_per_feature"],
            "kernel_avg_ms_unprofiled": j["roofline"]["kernel_avg_ms"],
-           "valu_busy_frac": counters["SQ_ACTIVE_INST_VALU"] / (counters["SQ_WAVE_CYCLES"] / 4.0) if "SQ_ACTIVE_INST_VALU" in counters else None,
-           "note": "rocprofv3 --pmc; SQ_WAVE_CYCLES / WAIT / ACTIVE are in quad-cycles summed over waves; valu_busy_frac = SQ_ACTIVE_INST_VALU / "
-                   "(SQ_WAVE_CYCLES / 4 wave slots per SIMD): the share of time a SIMD's VALU is issuing for this kernel"}
+           "valu_active_per_wave_slot_time": counters["SQ_ACTIVE_INST_VALU"] / counters["SQ_WAVE_CYCLES"] if "SQ_ACTIVE_INST_VALU" in counters else None,
+           "note": "rocprofv3 --pmc; SQ_WAVE_CYCLES / WAIT / ACTIVE are in quad-cycles summed over waves; valu_active_per_wave_slot_time = "
+                   "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (multiply by the resident waves per SIMD — 6 at w = 21 since round 3, 4 before — "
+                   "for a SIMD's view); valu_issue_frac (with the GRBM pass) = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x the launch's active "
+                   "cycles): the share of the launch in which a SIMD issues a VALU instruction of this kernel"}
     if gui_dir:
         g, _ = pmc_mean(gui_dir, "GRBM_GUI_ACTIVE", kernel)
         kt = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(find(gui_dir, "*kernel_trace.csv"))) if kernel in r["Kernel_Name"]]
         kt = [t for t in kt if t > 0.05 * max(kt)]
         out["GRBM_GUI_ACTIVE_per_launch"] = g
         out["effective_clock_GHz"] = g / 8.0 / (sum(kt) / len(kt))      # the counter sums the 8 XCDs; duration in ns
+        out["valu_issue_frac"] = counters["SQ_INSTS_VALU"] * 4.0 / (1024.0 * g / 8.0)   # passes are separate runs: a few per cent of launch-to-launch noise
     json.dump(out, open(os.path.join(here, tag + "_lk_chain_sq.json"), "w"), indent=1)
     print(out)
 
