@@ -81,6 +81,11 @@ struct svo_context {
     const uint8_t** h_ptrs = nullptr;            // pinned [SVO_RING][2][B]
     hipEvent_t ev_done[SVO_RING] = {}, ev_f0[SVO_RING] = {}, ev_lk0[SVO_RING] = {}, ev_lk1[SVO_RING] = {};
     hipEvent_t ev_pyr[SVO_RING] = {}, ev_tri[SVO_RING] = {};   // stage boundaries: pyramids built / world points triangulated
+    // many-sequence contexts build the NEXT frame's pyramids on a second stream while the current frame is in its LK kernel (issue_frame)
+    hipStream_t img_stream = nullptr;
+    hipEvent_t ev_img[SVO_RING] = {}, ev_begin = nullptr;
+    bool begin_recorded = false;
+    bool staged_inputs = false;                  // this frame's images were copied in on `stream` (host-image calls): the image stream must wait for them
     int head = 0, tail = 0, inflight = 0;        // ring indices: head = next to enqueue, tail = oldest outstanding
     int last_slot = -1;
     uint8_t* staging = nullptr;                  // device [2][B][W*H] for host-image calls
@@ -154,8 +159,8 @@ static int ctx_create(const svo_config* cfg_in, int device, int n_seq, int width
     int rc;
 #define ALLOC(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != SVO_OK) return rc;
     ALLOC(d.st, B);
-    ALLOC(d.pyr, B * 6 * (size_t)d.CN * (size_t)d.geom.pyr_bytes + 256);   // + slack: the LK kernel's unaligned dword loads may read a few bytes past a row
-    if (d.CN == 3) ALLOC(d.fastimg, B * 3 * (size_t)width * (size_t)height + 256);
+    ALLOC(d.pyr, B * 2 * SVO_PYR_SLOTS * (size_t)d.CN * (size_t)d.geom.pyr_bytes + 256);   // + slack: the LK kernel's unaligned dword loads may read a few bytes past a row
+    if (d.CN == 3) ALLOC(d.fastimg, B * SVO_PYR_SLOTS * (size_t)width * (size_t)height + 256);
     for (int k = 0; k < 2; k++) { ALLOC(d.feat_xy[k], B * CAP); ALLOC(d.feat_age[k], B * CAP); ALLOC(d.feat_str[k], B * CAP); }
     ALLOC(d.bucket_keys, B * (size_t)d.NB);
     ALLOC(d.bucket_rowcnt, B * (size_t)cfg.buckets_along_height); ALLOC(d.emit_ticket, B);
@@ -262,6 +267,9 @@ extern "C" void svo_destroy(svo_context* c) {
         if (c->ev_tri[i]) (void)hipEventDestroy(c->ev_tri[i]);
     }
     for (int i = 0; i < SVO_RING; i++) if (c->gexec[i]) (void)hipGraphExecDestroy(c->gexec[i]);
+    for (int i = 0; i < SVO_RING; i++) if (c->ev_img[i]) (void)hipEventDestroy(c->ev_img[i]);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->img_stream) (void)hipStreamDestroy(c->img_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -307,6 +315,26 @@ static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_e
     const uint8_t** dp = d.img_ptrs + (size_t)slot * 2 * B;         // the slot's pointer table: pinned host memory the kernel reads in place
     if (launch_front_fused(d, dp, stride, s)) {                        // lone stream: ingest + pyramid beside detection, two launches
         if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));   // stage timers: ms[0] = the fused front, ms[1] ~ 0
+    } else if (!c->capturing && ingest_ahead_applies(d)) {
+        // Many sequences: this frame's pyramids are built on the IMAGE stream, which only waits for the previous frame's reset — so,
+        // with frames in flight, they are built while the previous frame sits in its LK kernel.  That kernel fills six of a SIMD's
+        // eight wave slots and 480 of its 512 registers (svo_kernels_lk.hip): the ingest, pyramid and border kernels (11-17
+        // registers) are the ones that still fit beside it.  The frame's own stream then resets the state and goes on with detection.
+        if (!c->img_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&c->img_stream, hipStreamNonBlocking));   // (highest priority measured: same rate, but the two contexts' LK launches then run in lock-step)
+            HIPCHK(hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming));
+            for (int i = 0; i < SVO_RING; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_img[i], hipEventDisableTiming));
+        }
+        if (c->begin_recorded) HIPCHK(hipStreamWaitEvent(c->img_stream, c->ev_begin, 0));   // the fields k_pick_next reads are those of the frame in flight
+        if (c->staged_inputs) HIPCHK(hipStreamWaitEvent(c->img_stream, c->ev_f0[slot], 0));   // host-image call: the H2D copies were queued on `stream` before this frame's start event
+        launch_ingest_pyramid_ahead(d, dp, stride, c->img_stream);
+        HIPCHK(hipEventRecord(c->ev_img[slot], c->img_stream));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_img[slot], 0));
+        launch_frame_begin(d, s);
+        HIPCHK(hipEventRecord(c->ev_begin, s)); c->begin_recorded = true;
+        if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
+        launch_detect(d, 0, -1, s);
+        launch_detect(d, 1, -1, s);
     } else {
         launch_ingest_pyramid(d, dp, stride, s, true);                // + the per-frame reset
         if (with_events) HIPCHK(hipEventRecord(c->ev_pyr[slot], s));
@@ -383,6 +411,7 @@ static int enqueue_frame(svo_context* c, const uint8_t* const* left_dev, const u
     }
     if (!replayed) { const int rc = issue_frame(c, slot, stride, gn, c->stage_timing); if (rc != SVO_OK) return rc; }
     c->staged_slot[slot] = !replayed && c->stage_timing;
+    c->staged_inputs = false;
     HIPCHK(hipEventRecord(c->ev_done[slot], s));
     HIPCHK(hipGetLastError());
     c->head = (c->head + 1) % SVO_RING; c->inflight++;
@@ -481,6 +510,7 @@ static int stage_host_images(svo_context* c, const uint8_t* const* left, const u
     // pageable memory degenerates into per-row transfers: 3.5 ms per 1241x376 image).  All left images first, so that their
     // DMA runs while the CPU packs the right ones.
     lp.resize(B); rp.resize(B);
+    c->staged_inputs = true;
     for (int cam = 0; cam < 2; cam++) {
         const uint8_t* const* src = cam ? right : left;
         bool all_direct = (size_t)stride == rowb;

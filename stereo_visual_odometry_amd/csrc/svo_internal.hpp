@@ -9,6 +9,7 @@
 #define SVO_MAX_LEVELS 8
 #define SVO_RING 8            // results ring / max frames in flight
 #define SVO_MAX_WIN 31
+#define SVO_PYR_SLOTS 4       // T1, imageLeftT0_, lastLeftPyramid (which may be a stale third one, vo.cpp:179-181) + the next frame's, built ahead
 
 // A pyramid level is stored WITH its REFLECT_101 border, as cv::buildOpticalFlowPyramid stores it (withDerivatives = false,
 // pyrBorder = BORDER_REFLECT_101): `pad` pixels on every side, rows `stride` bytes apart.  The LK kernel then reads every window
@@ -26,7 +27,8 @@ struct Geometry {
 // Device-resident state of one sequence = the members of the reference's VisualOdometry (include/vo.h:233-269).
 struct SeqState {
     int frame_id;                             // vo.h:234
-    int slot_t1, slot_img_t0, slot_pyr_t0;    // which of the 3 pyramid slots holds T1 / imageLeftT0_ / lastLeftPyramid
+    int slot_t1, slot_img_t0, slot_pyr_t0;    // which of the SVO_PYR_SLOTS pyramid slots holds T1 / imageLeftT0_ / lastLeftPyramid
+    int slot_next;                            // slot the NEXT frame's pyramids were built in ahead of time (image stream of a many-sequence context), else unused
     int active;                               // this frame runs matching (frame_id > 0 when the frame began)
     int feat_buf;                             // which half of the feature double-buffer is current
     int n_feat;                               // currentVOFeatures.size()
@@ -59,7 +61,7 @@ struct DevBuffers {
     int bucket_h, bucket_w;
     float lk_mineig_cut;                       // LK: numerators below this fail the minimum-eigenvalue test (see lk_mineig_cut())
     SeqState* st;                              // [B]
-    uint8_t* pyr;                              // [B][3 slots][2 cams][CN planes][pyr_bytes]
+    uint8_t* pyr;                              // [B][SVO_PYR_SLOTS][2 cams][CN planes][pyr_bytes]
     uint8_t* fastimg;                          // CN == 3 only: [B][3 slots][W*H] the first W bytes of every interleaved left row —
                                                // the single-channel 'image' cv::FAST sees in a BGR Mat
     float2* feat_xy[2]; int* feat_age[2]; int* feat_str[2];   // [B][CAP] each, double-buffered
@@ -93,10 +95,10 @@ struct DevBuffers {
 
 // plane 0 of the pyramid of (sequence, slot, camera); plane k follows at + k * geom.pyr_bytes
 __host__ __device__ inline size_t pyr_index(const DevBuffers& d, int seq, int slot, int cam) {
-    return ((size_t)(seq * 3 + slot) * 2 + cam) * (size_t)d.CN * (size_t)d.geom.pyr_bytes;
+    return ((size_t)(seq * SVO_PYR_SLOTS + slot) * 2 + cam) * (size_t)d.CN * (size_t)d.geom.pyr_bytes;
 }
 __host__ __device__ inline size_t fastimg_index(const DevBuffers& d, int seq, int slot) {
-    return (size_t)(seq * 3 + slot) * (size_t)d.geom.W * (size_t)d.geom.H;
+    return (size_t)(seq * SVO_PYR_SLOTS + slot) * (size_t)d.geom.W * (size_t)d.geom.H;
 }
 
 // Hypotheses of the first RANSAC chunk (always solved).  16 when many sequences share the GPU; 32 for a lone stream: the GPU is
@@ -113,6 +115,12 @@ void launch_pyramid(const DevBuffers& d, hipStream_t s);                 // leve
 void launch_pad_pyramid(const DevBuffers& d, hipStream_t s);             // REFLECT_101 borders of every level of the T1 slot (both cameras, every plane)
 int lk_pad_for(int win);                                                 // border width the LK kernel's reads need at this window (svo_kernels_lk.hip)
 void launch_ingest_pyramid(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride_bytes, hipStream_t s, bool begin_frame);   // both, fewer launches
+// The same for the NEXT frame, on another stream, while the current frame is still being processed: the pyramids go into the slot no
+// field of the sequence state refers to (SeqState::slot_next) and nothing else of the state is touched; launch_frame_begin (on the
+// frame's own stream, after that work) then performs the per-frame reset with that slot as T1.  Single-channel contexts with >= 2 levels.
+bool ingest_ahead_applies(const DevBuffers& d);
+void launch_ingest_pyramid_ahead(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride_bytes, hipStream_t s);
+void launch_frame_begin(const DevBuffers& d, hipStream_t s);
 void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s);   // pass 0: FAST_THRESHOLD, pass 1: /4 if needed; th_override >= 0 replaces it
 // grid_n = max features that can enter LK; early_out: a feature stops at its first pass with status 0 (frame pipeline) or runs all four (member call)
 bool launch_lk_chain(const DevBuffers& d, int grid_n, hipStream_t s, int early_out);   // false: no kernel built for this (window, lanes, channels) — nothing ran

@@ -24,10 +24,17 @@ __device__ __forceinline__ int free_slot(const SeqState& s) {
     for (int c = 0; c < 3; c++) if (c != s.slot_img_t0 && c != s.slot_pyr_t0) { t1 = c; break; }
     return t1;
 }
-__device__ __forceinline__ void frame_begin(SeqState& s) {
+// the slot no field refers to while a frame is in flight: where the NEXT frame's pyramids can be built ahead of time.  Read at any
+// moment of the current frame (even while k_frame_end rewrites the fields: the set in use only shrinks there) it is free.
+__device__ __forceinline__ int next_slot(const SeqState& s) {
+    const int a = s.slot_img_t0, b = s.slot_pyr_t0, t = s.slot_t1;
+    for (int c = 0; c < SVO_PYR_SLOTS; c++) if (c != a && c != b && c != t) return c;
+    return 0;
+}
+__device__ __forceinline__ void frame_begin(SeqState& s, int t1 = -1) {
     s.n_old = s.n_feat;
     s.active = s.frame_id > 0;
-    s.slot_t1 = free_slot(s);
+    s.slot_t1 = t1 >= 0 ? t1 : free_slot(s);
     s.do_second = 0; s.n_lk = 0; s.n_tracks = 0; s.n_circ = 0; s.n_inliers = 0; s.ok = 0;
     s.pnp_best = -1; s.pnp_iters = 0; s.pnp_good = 0; s.pnp_drawn = 0;
     s.fail_reason = s.active ? 0 : 1;
@@ -123,11 +130,11 @@ void launch_ingest(const DevBuffers& d, const uint8_t* const* left_right_dev_ptr
 // ------------------------------------------------------------------------------------------------
 #define PD_TW 32
 #define PD_TH 8
-__global__ __launch_bounds__(256) void k_pyrdown(DevBuffers d, int level) {
+__global__ __launch_bounds__(256) void k_pyrdown(DevBuffers d, int level, int ahead) {
     const int plane = blockIdx.z % d.CN, sc = blockIdx.z / d.CN;          // every colour plane is its own pyramid
     const int seq = sc / 2, cam = sc & 1;
     const LevelInfo ls = d.geom.lv[level - 1], ld = d.geom.lv[level];
-    uint8_t* base = d.pyr + pyr_index(d, seq, d.st[seq].slot_t1, cam) + (size_t)plane * d.geom.pyr_bytes;
+    uint8_t* base = d.pyr + pyr_index(d, seq, ahead ? d.st[seq].slot_next : d.st[seq].slot_t1, cam) + (size_t)plane * d.geom.pyr_bytes;
     const uint8_t* src = base + ls.off;
     uint8_t* dst = base + ld.off;
     constexpr int SW = 2 * PD_TW + 3, SH = 2 * PD_TH + 3;        // 67 x 19 source tile
@@ -176,8 +183,10 @@ static __device__ __forceinline__ void ingest_pyr1_body(const DevBuffers& d, con
     const int seq = bz >> 1, cam = bz & 1;
     const LevelInfo ls = d.geom.lv[0], ld = d.geom.lv[1];
     const uint8_t* src = srcs[cam * d.B + seq];
-    const int slot = begin_frame ? free_slot(d.st[seq]) : d.st[seq].slot_t1;
-    if (begin_frame && bx == 0 && by == 0 && cam == 0 && threadIdx.x == 0) frame_begin(d.st[seq]);
+    // begin_frame: 0 = into the T1 slot as it stands (stage entry points), 1 = the frame pipeline's own ingest (free slot + the per-frame
+    // reset), 2 = ahead of the frame (image stream): into SeqState::slot_next, which k_pick_next chose; nothing of the state is written
+    const int slot = begin_frame == 2 ? d.st[seq].slot_next : begin_frame ? free_slot(d.st[seq]) : d.st[seq].slot_t1;
+    if (begin_frame == 1 && bx == 0 && by == 0 && cam == 0 && threadIdx.x == 0) frame_begin(d.st[seq]);
     uint8_t* base = d.pyr + pyr_index(d, seq, slot, cam);
     uint8_t* l0 = base + ls.off; uint8_t* dst = base + ld.off;
     constexpr int SW = 2 * PD_TW + 3, SH = 2 * PD_TH + 3;        // 67 x 19 source tile
@@ -236,11 +245,11 @@ __global__ __launch_bounds__(256) void k_ingest_pyr1(DevBuffers d, const uint8_t
 // REFLECT_101 folds them onto positions inside the tile.
 #define P2_TW 16
 #define P2_TH 8
-static __device__ __forceinline__ void pyrdown2_body(const DevBuffers& d, int level, int bx, int by, int bz) {
+static __device__ __forceinline__ void pyrdown2_body(const DevBuffers& d, int level, int bx, int by, int bz, int ahead = 0) {
     const int plane = bz % d.CN, sc = bz / d.CN;
     const int seq = sc / 2, cam = sc & 1;
     const LevelInfo ls = d.geom.lv[level], lm = d.geom.lv[level + 1], ld = d.geom.lv[level + 2];
-    uint8_t* base = d.pyr + pyr_index(d, seq, d.st[seq].slot_t1, cam) + (size_t)plane * d.geom.pyr_bytes;
+    uint8_t* base = d.pyr + pyr_index(d, seq, ahead ? d.st[seq].slot_next : d.st[seq].slot_t1, cam) + (size_t)plane * d.geom.pyr_bytes;
     const uint8_t* src = base + ls.off;
     uint8_t* mid = base + lm.off; uint8_t* dst = base + ld.off;
     constexpr int MW = 2 * P2_TW + 3, MH = 2 * P2_TH + 3;        // 35 x 19 of the middle level
@@ -297,19 +306,19 @@ static __device__ __forceinline__ void pyrdown2_body(const DevBuffers& d, int le
         }
     }
 }
-__global__ __launch_bounds__(256) void k_pyrdown2(DevBuffers d, int level) { pyrdown2_body(d, level, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(256) void k_pyrdown2(DevBuffers d, int level, int ahead) { pyrdown2_body(d, level, blockIdx.x, blockIdx.y, blockIdx.z, ahead); }
 
 // k_pad_pyramid: the REFLECT_101 border of every level of the T1 slot — what cv::buildOpticalFlowPyramid's copyMakeBorder leaves
 // around each level (pyrBorder = BORDER_REFLECT_101).  One thread per border pixel: the ring of a level is cut into its top and
 // bottom bands (pad rows of the padded width) and its left and right bands (h rows of pad pixels); pixel (x, y) outside the level
 // takes level(reflect101(y), reflect101(x)) — the same index function the LK kernel's per-byte border path used before the border
 // was materialised, so the values it sees are the same bytes.
-__global__ __launch_bounds__(256) void k_pad_pyramid(DevBuffers d) {
+__global__ __launch_bounds__(256) void k_pad_pyramid(DevBuffers d, int ahead) {
     const int plane = blockIdx.z % d.CN, sc = blockIdx.z / d.CN;
     const int seq = sc / 2, cam = sc & 1, level = blockIdx.y;
     const LevelInfo L = d.geom.lv[level];
     const int P = d.geom.pad;
-    uint8_t* img = d.pyr + pyr_index(d, seq, d.st[seq].slot_t1, cam) + (size_t)plane * d.geom.pyr_bytes + L.off;
+    uint8_t* img = d.pyr + pyr_index(d, seq, ahead ? d.st[seq].slot_next : d.st[seq].slot_t1, cam) + (size_t)plane * d.geom.pyr_bytes + L.off;
     const int pw = L.w + 2 * P, band = P * pw, side = L.h * P;
     const int total = 2 * band + 2 * side;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
@@ -319,24 +328,25 @@ __global__ __launch_bounds__(256) void k_pad_pyramid(DevBuffers d) {
         img[(ptrdiff_t)y * L.stride + x] = img[(size_t)reflect101(y, L.h) * L.stride + reflect101(x, L.w)];
     }
 }
-void launch_pad_pyramid(const DevBuffers& d, hipStream_t st) {
+static void launch_pad_pyramid_into(const DevBuffers& d, hipStream_t st, int ahead) {
     const LevelInfo& L0 = d.geom.lv[0];
     const int P = d.geom.pad, ring0 = 2 * P * (L0.w + 2 * P) + 2 * P * L0.h;
     int gx = (ring0 + 4 * 256 - 1) / (4 * 256); if (gx < 1) gx = 1; if (gx > 64) gx = 64;      // ~4 border pixels per thread at level 0
-    hipLaunchKernelGGL(k_pad_pyramid, dim3(gx, d.geom.nlevels, d.B * 2 * d.CN), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_pad_pyramid, dim3(gx, d.geom.nlevels, d.B * 2 * d.CN), dim3(256), 0, st, d, ahead);
 }
+void launch_pad_pyramid(const DevBuffers& d, hipStream_t st) { launch_pad_pyramid_into(d, st, 0); }
 
 // levels first .. nlevels-1 from level first-1: pairs of levels per launch where two remain
-static void launch_pyramid_from(const DevBuffers& d, int first, hipStream_t st) {
+static void launch_pyramid_from(const DevBuffers& d, int first, hipStream_t st, int ahead = 0) {
     int l = first;
     while (l < d.geom.nlevels) {
         if (l + 1 < d.geom.nlevels) {
             dim3 g((d.geom.lv[l + 1].w + P2_TW - 1) / P2_TW, (d.geom.lv[l + 1].h + P2_TH - 1) / P2_TH, d.B * 2 * d.CN);
-            hipLaunchKernelGGL(k_pyrdown2, g, dim3(256), 0, st, d, l - 1);
+            hipLaunchKernelGGL(k_pyrdown2, g, dim3(256), 0, st, d, l - 1, ahead);
             l += 2;
         } else {
             dim3 g((d.geom.lv[l].w + PD_TW - 1) / PD_TW, (d.geom.lv[l].h + PD_TH - 1) / PD_TH, d.B * 2 * d.CN);
-            hipLaunchKernelGGL(k_pyrdown, g, dim3(256), 0, st, d, l);
+            hipLaunchKernelGGL(k_pyrdown, g, dim3(256), 0, st, d, l, ahead);
             l += 1;
         }
     }
@@ -353,6 +363,32 @@ void launch_ingest_pyramid(const DevBuffers& d, const uint8_t* const* left_right
     }
     launch_ingest(d, left_right_dev_ptrs, stride, st, begin_frame);
     launch_pyramid(d, st);
+}
+
+// ---- the next frame's pyramids, ahead of the frame (many-sequence contexts; svo_api.hip issue_frame) ----
+// k_pick_next: one thread per sequence names the slot (a single decision per sequence: the blocks of the ingest that follows must
+// all write the same one, whatever k_frame_end of the frame in flight does to the fields meanwhile).
+__global__ void k_pick_next(DevBuffers d) {
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq < d.B) d.st[seq].slot_next = next_slot(d.st[seq]);
+}
+__global__ void k_frame_begin(DevBuffers d) {
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq < d.B) frame_begin(d.st[seq], d.st[seq].slot_next);
+}
+bool ingest_ahead_applies(const DevBuffers& d) {
+    static const bool off = getenv("SVO_INGEST_AHEAD") && atoi(getenv("SVO_INGEST_AHEAD")) == 0;
+    return !off && d.B > SVO_LONE_MAX_SEQ && d.CN == 1 && d.geom.nlevels >= 2;
+}
+void launch_ingest_pyramid_ahead(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride, hipStream_t st) {
+    hipLaunchKernelGGL(k_pick_next, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
+    dim3 g((d.geom.lv[1].w + PD_TW - 1) / PD_TW, (d.geom.lv[1].h + PD_TH - 1) / PD_TH, d.B * 2);
+    hipLaunchKernelGGL(k_ingest_pyr1, g, dim3(256), 0, st, d, left_right_dev_ptrs, stride, 2);
+    launch_pyramid_from(d, 2, st, 1);
+    launch_pad_pyramid_into(d, st, 1);
+}
+void launch_frame_begin(const DevBuffers& d, hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_begin, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
 }
 
 // ------------------------------------------------------------------------------------------------
