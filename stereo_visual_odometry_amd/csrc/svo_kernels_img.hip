@@ -578,6 +578,19 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* img_single, int w_s
     fast_body<MODE>(img_single, w_single, h_single, score_out, d, pass, threshold, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }
 
+// The SECOND detection pass of a many-sequence context: launched every frame, needed by a sequence that kept < 100 features (vo.cpp:327)
+// — on a healthy scene by none.  One block per tile and sequence (123 000 blocks at 256 sequences) costs 0.15-0.25 ms on the frame's
+// critical chain just to look at do_second and leave; here a sequence gets FAST_STRIDED_BLOCKS blocks that walk its tiles.
+#define FAST_STRIDED_BLOCKS 32
+__global__ __launch_bounds__(256) void k_fast_strided(DevBuffers d, int pass, int threshold, int fx, int fy) {
+    const SeqState& s = d.st[blockIdx.z];
+    if (pass == 0 ? !(s.frame_id > 0) : !s.do_second) return;
+    for (int t = blockIdx.x; t < fx * fy; t += gridDim.x) {
+        fast_body<0>(nullptr, 0, 0, nullptr, d, pass, threshold, t % fx, t / fx, blockIdx.z, fx, fy);
+        __syncthreads();                                              // the tile arrays in LDS are reused by the next tile
+    }
+}
+
 void launch_fast_score_map(const uint8_t* img_dev, int w, int h, int threshold, uint8_t* score_dev, hipStream_t st) {
     DevBuffers dummy = {};
     dim3 g((w + FT_W - 1) / FT_W, (h + FT_H - 1) / FT_H, 1);
@@ -705,6 +718,17 @@ static __device__ __forceinline__ void bucket_emit_body(const DevBuffers& d, int
     }
 }
 __global__ __launch_bounds__(EMIT_THREADS) void k_bucket_emit(DevBuffers d, int pass) { bucket_emit_body(d, pass, blockIdx.x, blockIdx.y, gridDim.x); }
+// the same with EMIT_STRIDED_BLOCKS blocks per sequence walking the grid rows (the second pass of many-sequence contexts, see
+// k_fast_strided): the ticket still counts ROWS, so the block that finishes the last row publishes
+#define EMIT_STRIDED_BLOCKS 8
+__global__ __launch_bounds__(EMIT_THREADS) void k_bucket_emit_strided(DevBuffers d, int pass, int n_rows) {
+    const SeqState& s = d.st[blockIdx.y];
+    if (pass == 0 ? !s.active : !s.do_second) return;
+    for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        bucket_emit_body(d, pass, row, blockIdx.y, n_rows);
+        __syncthreads();
+    }
+}
 
 // ---- the front of a lone stream's frame in two launches instead of four.  Ingest + pyramid and detection are independent
 // chains (FAST runs on the PREVIOUS left image, vo.cpp:325): on a nearly empty GPU their kernels ran one after the other, each
@@ -876,6 +900,12 @@ void launch_detect(const DevBuffers& d, int pass, int th_override, hipStream_t s
     if (d.cfg.features_per_bucket > 1) { launch_detect_general(d, pass, th, st); return; }
     // pass 0: k_fast offers the existing tracks itself; pass 1 finds them offered (and n_old set) by the last block of pass 0's emit
     dim3 g((d.geom.W + FT_W - 1) / FT_W, (d.geom.H + FT_H - 1) / FT_H, d.B);
+    static const bool strided_off = getenv("SVO_SECOND_PASS_STRIDED") && atoi(getenv("SVO_SECOND_PASS_STRIDED")) == 0;
+    if (pass == 1 && d.B > SVO_LONE_MAX_SEQ && !strided_off) {
+        hipLaunchKernelGGL(k_fast_strided, dim3(FAST_STRIDED_BLOCKS, 1, d.B), dim3(256), 0, st, d, pass, th, (int)g.x, (int)g.y);
+        hipLaunchKernelGGL(k_bucket_emit_strided, dim3(EMIT_STRIDED_BLOCKS, d.B), dim3(EMIT_THREADS), 0, st, d, pass, d.cfg.buckets_along_height);
+        return;
+    }
     hipLaunchKernelGGL(k_fast<0>, g, dim3(256), 0, st, (const uint8_t*)nullptr, 0, 0, (uint8_t*)nullptr, d, pass, th);
     hipLaunchKernelGGL(k_bucket_emit, dim3(d.cfg.buckets_along_height, d.B), dim3(EMIT_THREADS), 0, st, d, pass);
 }

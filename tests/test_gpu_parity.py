@@ -675,6 +675,51 @@ def test_stereo_callback_failure_paths_parity(api):
     assert 4 in reasons[3:]                                  # the 0.1 m gate rejects the 0.4 m steps
 
 
+def test_many_sequence_context_failure_paths_and_second_pass(api):
+    """The failure paths inside a context of more than 8 sequences, frames submitted ahead (two in flight): such a context builds
+    the next frame's pyramids on a second stream into a fourth pyramid slot (k_pick_next / k_frame_begin) and runs the second
+    detection pass with strided kernels.  Sequences 0-4 replay black frames first (second FAST pass, empty feature set, the stale
+    lastLeftPyramid of vo.cpp:179-181 next to a fresh imageLeftT0_ — the case that needs all four slots), sequences 5-9 start on
+    the scene at once; every sequence must give the oracle's flags, counters, feature sets and pose, frame by frame."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    import torch
+    cal = dict(syn.KITTI00, width=480, height=200, cx=240.0, cy=100.0)
+    over = dict(win_w=21, win_h=21, max_translation_norm=2.0)
+    sq = syn.StereoSequence(cal=cal, n_frames=5, seed=11, step=0.3)
+    black = np.zeros_like(sq.left[0])
+    streams = [([black, black] + sq.left[:4], [black, black] + sq.right[:4]),      # black, black, then the scene
+               (sq.left + [sq.left[4]], sq.right + [sq.right[4]])]                  # the scene, last frame repeated (zero motion)
+    Pl, Pr = syn.projection_matrices(cal)
+    want = []
+    for L, R in streams:
+        o = orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl, Pr)
+        per = []
+        for k in range(6):
+            ok, T = o.stereo_callback(L[k], R[k])
+            per.append((ok, T.copy(), {f[0]: getattr(o.stats, f[0]) for f in o.stats._fields_}, [a.copy() for a in o.features()]))
+        want.append(per)
+    assert want[0][1][2]["second_pass"] == 1
+    B = 10
+    vo = api.BatchVisualOdometry(480, 200, B, api.default_config(**over)); vo.initalize_projection_matricies(Pl, Pr)
+    which = lambda i: 0 if i < 5 else 1
+    dev = [[(torch.from_numpy(np.ascontiguousarray(L[k])).cuda(), torch.from_numpy(np.ascontiguousarray(R[k])).cuda()) for k in range(6)] for L, R in streams]
+    torch.cuda.synchronize()
+    submit = lambda k: vo.submit_device([dev[which(i)][k][0].data_ptr() for i in range(B)], [dev[which(i)][k][1].data_ptr() for i in range(B)], 480)
+    submit(0)
+    for k in range(6):
+        if k + 1 < 6:
+            submit(k + 1)                                            # the next frame is in flight before this one is collected
+        ok, T = vo.collect()
+        for i in range(B):
+            w = want[which(i)][k]
+            sg = vo.stats[i].as_dict()
+            assert bool(ok[i]) == w[0] and sg == w[2], (k, i, sg, w[2])
+            assert np.abs(T[i][:3, 3] - w[1][:3, 3]).max() < POSE_TOL_T and rot_angle(T[i][:3, :3], w[1][:3, :3]) < POSE_TOL_R
+    for i in (0, 4, 5, 9):
+        f = vo.features(i); w = want[which(i)][5][3]
+        assert np.array_equal(bits(f[0]), bits(w[0])) and np.array_equal(f[1], w[1]) and np.array_equal(f[2], w[2])
+
+
 def test_kitti_shaped_frame_parity(api):
     """full BASELINE cfg2 size (1241x376, 21x21 window, 3 levels), two frames."""
     from stereo_visual_odometry_amd import synthetic as syn
