@@ -143,8 +143,8 @@ int svo_circular_matching(svo_context* ctx, const uint8_t* left_t1, const uint8_
  * section 2 — so such contexts simply take turns; builds that leave >= 96 (w = 31, 3-channel contexts) keep the overlap scheme.  A
  * test pins the figure, so that a change to the LK kernel that alters the regime fails loudly.
  * NOTE on locality: creating or destroying ANOTHER context with more than 8 sequences on the same device changes which builds of
- * the PnP / triangulation kernels this context launches from its next frame on (full-register alone, 96-register when the
- * device is shared) and whether its LK launches are chained behind the other's.  Results are identical either way. */
+ * the PnP / triangulation kernels this context launches from its next frame on (full-register alone; 96-register when the
+ * device is shared and the figure above is >= 96) and chains its LK launches behind the other's.  Results are identical either way. */
 int svo_get_lk_registers_left(svo_context* ctx);
 
 int svo_submit_batch(svo_context* ctx, const uint8_t* const* left_dev, const uint8_t* const* right_dev, int stride);

@@ -233,14 +233,21 @@ extern "C" int svo_create(const svo_config* cfg, int device, int n_seq, int widt
     return ctx_create(cfg, device, n_seq, width, height, 0, out);
 }
 
-// Chaining the LK launches and running the f64 kernels as 96-register builds pays only if those builds fit beside a resident LK
-// grid (lk_registers_left: w = 21 yes, w = 10 no — there the contexts' LK grids are left to overlap each other, measured +3 %).
-// `contexts` is an atomic: contexts are created and destroyed on other threads while this one enqueues frames; a frame reads it
-// ONCE (issue_frame) and uses that one answer for both decisions it drives (the 96-register builds and the chained LK launches).
-static bool lk_gated(const svo_context* c) {
+// Several many-sequence contexts on one device.  Two decisions, both read ONCE per frame (issue_frame); `contexts` is an atomic:
+// contexts are created and destroyed on other threads while this one enqueues frames.
+//  * lk_gated: the f64 kernels run as 96-register builds under the OTHER context's LK grid — only if those builds fit beside it
+//    (lk_registers_left >= 96: w = 31 and the 3-channel builds; not w = 21 since round 3, nor w = 10 / 15).
+//  * lk_chained: the contexts' LK launches wait for each other (one event per device).  Always, when the device is shared: two
+//    LK grids resident together only share the CUs — measured the same whole-job rate either way at w = 21 (18 370 vs 18 390
+//    frame-pairs/s) — and unchained each launch's duration contains a part of the other's (12.7 ms per launch chained, 13.3-16.4
+//    unchained, varying from run to run), which makes the per-launch figure of the dominant kernel, the one the bench line's
+//    roofline is computed from, meaningless.  SVO_LK_GATE=0 switches both off (measurement).
+static bool lk_shared_device(const svo_context* c) {
     static const bool off = getenv("SVO_LK_GATE") && atoi(getenv("SVO_LK_GATE")) == 0;
-    return !off && c->counted && c->lk_room >= 96 && g_lk_gate[c->device].contexts.load(std::memory_order_relaxed) > 1;
+    return !off && c->counted && g_lk_gate[c->device].contexts.load(std::memory_order_relaxed) > 1;
 }
+static bool lk_gated(const svo_context* c) { return c->lk_room >= 96 && lk_shared_device(c); }
+static bool lk_chained(const svo_context* c) { return lk_shared_device(c); }
 
 extern "C" void svo_destroy(svo_context* c) {
     if (!c) return;
@@ -341,7 +348,7 @@ static int issue_frame(svo_context* c, int slot, int stride, int gn, bool with_e
         launch_detect(d, 0, -1, s);
         launch_detect(d, 1, -1, s);
     }
-    const bool gated = !c->capturing && shares_device;
+    const bool gated = !c->capturing && (shares_device || lk_chained(c));   // chained LK launches (a captured graph cannot wait for another stream's event)
     if (gated) {
         LkGate& g = g_lk_gate[c->device];
         std::lock_guard<std::mutex> lock(g.mu);
