@@ -980,12 +980,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_compact(DevBuffers d) {
     const int n = s.n_lk, fb = s.feat_buf;
     const size_t o = (size_t)seq * d.CAP;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nthr = blockDim.x, nwv = nthr >> 6;                    // 1024 threads for a lone stream (fewest rounds), 256 for many sequences (below)
     const float2* fxy = d.feat_xy[fb] + o; const int* fage = d.feat_age[fb] + o; const int* fstr = d.feat_str[fb] + o;
     float2* nxy = d.feat_xy[fb ^ 1] + o; int* nage = d.feat_age[fb ^ 1] + o; int* nstr = d.feat_str[fb ^ 1] + o;
     int run = 0, cntc = 0;
     unsigned visits = 0, steps = 0;                                  // svo_frame_stats.lk_level_visits / lk_newton_steps
     unsigned dead0 = 0, dead1 = 0, dead2 = 0;                        // svo_frame_stats.lk_dead_after_pass: features that first failed in pass 0, 1, 2
-    for (int base = 0; base < n; base += SCAN_THREADS) {
+    for (int base = 0; base < n; base += nthr) {
         const int i = base + threadIdx.x;
         uint8_t m = 0;
         if (i < n) {
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_compact(DevBuffers d) {
         if (lane == 0) sh_cnt[wv] = __popcll(bal);
         __syncthreads();
         int pos = run + __popcll(bal & ((1ull << lane) - 1ull));
-        for (int w = 0; w < SCAN_WAVES; w++) { const int c = sh_cnt[w]; if (w < wv) pos += c; run += c; }
+        for (int w = 0; w < nwv; w++) { const int c = sh_cnt[w]; if (w < wv) pos += c; run += c; }
         if (keep) {
             d.tl0[o + pos] = d.pl0[o + i]; d.tl1[o + pos] = d.pl1[o + i];
             d.tr1[o + pos] = d.pr1[o + i]; d.tr0[o + pos] = d.pr0[o + i];
@@ -1017,7 +1018,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_compact(DevBuffers d) {
     __syncthreads();
     if (threadIdx.x == 0) {
         int total_c = 0;
-        for (int w = 0; w < SCAN_WAVES; w++) total_c += sh_c[w];
+        for (int w = 0; w < nwv; w++) total_c += sh_c[w];
         if (n > 0) {
             s.n_tracks = run; s.n_circ = total_c; s.n_feat = run; s.feat_buf = fb ^ 1;
         } else {
@@ -1035,7 +1036,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_compact(DevBuffers d) {
     }
 }
 void launch_compact(const DevBuffers& d, hipStream_t st) {
-    hipLaunchKernelGGL(k_compact, dim3(d.B), dim3(SCAN_THREADS), 0, st, d);
+    // A 1024-thread block needs four free wave slots on every SIMD of one CU at the same moment.  Beside other resident kernels — the
+    // tail of an LK grid, the image stream's kernels of a many-sequence context — that moment comes late: traces show this kernel
+    // waiting 0.8-1.6 ms for 20 us of work.  Many-sequence contexts launch it with 256 threads (four times the rounds, no waiting).
+    const int threads = d.B > SVO_LONE_MAX_SEQ ? 256 : SCAN_THREADS;
+    hipLaunchKernelGGL(k_compact, dim3(d.B), dim3(threads), 0, st, d);
 }
 
 // findClosePoints (vo.cpp:265-280) as a stand-alone stage
