@@ -996,6 +996,63 @@ def test_full_size_properties_determinism_and_slot_independence(api):
 
 
 FUZZ_CASES = int(os.environ.get("SVO_FUZZ_CASES", "16"))          # the suite runs 16; SVO_FUZZ_CASES=400 for a one-off sweep
+FUZZ_BATCH_CASES = int(os.environ.get("SVO_FUZZ_BATCH_CASES", "4"))  # many-sequence contexts; SVO_FUZZ_BATCH_CASES=100 for a sweep
+
+
+@pytest.mark.parametrize("case", range(FUZZ_BATCH_CASES))
+def test_fuzz_many_sequence_contexts(api, case):
+    """Seeded random configurations of the MANY-SEQUENCE path (contexts of 9-14 sequences: pyramids of the next frame built ahead
+    on a second stream into a fourth slot, strided second detection pass, 256-thread compaction): any LK window, 2-5 levels, 1-3
+    frames in flight, two frame streams per context — one of them with black frames spliced in at random times (empty feature
+    sets, second passes, stale pyramids, recoveries) — every sequence against the oracle, frame by frame."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    import torch
+    rng = np.random.default_rng(31000 + case)
+    w, h = int(rng.choice([320, 352, 417])), int(rng.choice([160, 176, 203]))
+    cal = dict(syn.KITTI00, width=w, height=h, cx=w / 2.0, cy=h / 2.0)
+    NF = 6
+    win = int(rng.choice([10, 15, 21, 21])) if case < 4 else int(rng.integers(5, 32))
+    over = dict(win_w=win, win_h=win, max_level=int(rng.integers(1, 5)), fast_threshold=int(rng.choice([12, 20, 35])),
+                ransac_iterations=int(rng.choice([50, 100])), lk_max_count=int(rng.choice([10, 30])), max_translation_norm=2.0)
+    Pl, Pr = syn.projection_matrices(cal)
+    streams = []
+    for j in range(2):
+        sq = syn.StereoSequence(cal=cal, n_frames=NF, seed=7000 + 2 * case + j, step=float(rng.uniform(0.1, 0.4)),
+                                movers=float(rng.choice([0.0, 0.3])), cell_px=float(rng.uniform(10.0, 20.0)))
+        L, R = list(sq.left), list(sq.right)
+        if j == 1:
+            black = np.zeros_like(L[0])
+            for b in rng.choice(NF, size=int(rng.integers(1, 3)), replace=False):
+                L[int(b)] = black; R[int(b)] = black
+        streams.append((L, R))
+    want = []
+    for L, R in streams:
+        o = orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl, Pr)
+        per = []
+        for k in range(NF):
+            ok, T = o.stereo_callback(L[k], R[k])
+            per.append((ok, T.copy(), {f[0]: getattr(o.stats, f[0]) for f in o.stats._fields_}, [a.copy() for a in o.features()]))
+        want.append(per)
+    B, depth = int(rng.integers(9, 15)), int(rng.integers(1, 4))
+    vo = api.BatchVisualOdometry(w, h, B, api.default_config(**over)); vo.initalize_projection_matricies(Pl, Pr)
+    which = lambda i: (i * 7 + case) % 2
+    dev = [[(torch.from_numpy(np.ascontiguousarray(L[k])).cuda(), torch.from_numpy(np.ascontiguousarray(R[k])).cuda()) for k in range(NF)] for L, R in streams]
+    torch.cuda.synchronize()
+    sub = 0
+    for k in range(NF):
+        while sub < NF and sub - k < depth:
+            vo.submit_device([dev[which(i)][sub][0].data_ptr() for i in range(B)], [dev[which(i)][sub][1].data_ptr() for i in range(B)], w)
+            sub += 1
+        ok, T = vo.collect()
+        for i in range(B):
+            wnt = want[which(i)][k]
+            sg = vo.stats[i].as_dict()
+            assert bool(ok[i]) == wnt[0] and sg == wnt[2], (case, over, B, depth, k, i, sg, wnt[2])
+            assert np.abs(T[i][:3, 3] - wnt[1][:3, 3]).max() < POSE_TOL_T and rot_angle(T[i][:3, :3], wnt[1][:3, :3]) < POSE_TOL_R
+    for i in (0, 1, B - 1):
+        f = vo.features(i); wnt = want[which(i)][NF - 1][3]
+        assert np.array_equal(bits(f[0]), bits(wnt[0])) and np.array_equal(f[1], wnt[1]) and np.array_equal(f[2], wnt[2])
+    vo.close()
 
 
 @pytest.mark.parametrize("case", range(FUZZ_CASES))
