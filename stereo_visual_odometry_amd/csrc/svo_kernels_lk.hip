@@ -284,49 +284,83 @@ __device__ __forceinline__ void load_pairs(const uint8_t* __restrict__ p, unsign
 //       lanes (k, x|y); the tail adds (float)(diff * I) to ib; at the end ib1 += (k0x + k2x) + (k1x + k3x).
 // Measured against the reference's own recording (tools/deviation_ablation.py): this order reproduces run1/result.csv digit for
 // digit, the exact-integer sums of the default mode flip borderline tracks at frames 14, 15, 22, 23.
-// Mapping: the owner lanes write their per-element integers to LDS ([row][e]); five CHAIN lanes per sum (four SIMD lanes + the
-// tail) walk their elements in OpenCV's order with one dependent float add each — a serial chain by construction (105 adds for
-// the tail at W = 21), which is why this mode costs several times the default's Newton step and is opt-in.
-#ifndef FS_UNROLL
-#define FS_UNROLL 7
-#endif
+// Mapping (three phases; the block is one wave): the owner lanes write their per-element integers to LDS ([row][e]); a CONVERT
+// phase, one lane per (sum, window row), turns them into the floats OpenCV adds — fx * fy for A, (float)(p[k] + p[k + 4]) or
+// (float)p for b, every one an independent rounding — and stores them in CHAIN ORDER, one contiguous array per chain; five chain
+// lanes per sum (the four SIMD float lanes + the scalar tail) then walk their arrays with 16-byte LDS reads and ONE dependent
+// float add per element.  The chain is serial by construction (105 adds for the tail at W = 21), which is why this mode costs a
+// multiple of the default's Newton step and is opt-in; everything that is not the chain runs on parallel lanes.  (First version:
+// the chain lanes converted, multiplied and selected per element themselves — about six instructions and one or two LDS reads per
+// element on a wave with 10-15 live lanes; DESIGN.md has the A/B.)
 template <int W, int CN> struct LkFs {
+    static constexpr int up4(int v) { return (v + 3) & ~3; }
     static constexpr int E = W * CN, NSIMD = (E / 8) * 8;
-    static constexpr int CNT_S = NSIMD / 4, CNT_T = E - NSIMD, MAXC = CNT_S > CNT_T ? CNT_S : CNT_T;     // A: elements per row of a SIMD / the tail chain
-    static constexpr int NG = NSIMD / 8, MAXB = NG > CNT_T ? NG : CNT_T;                               // b: items per row
-    static constexpr int LDS_INTS = 2 * W * E;
+    static constexpr int CNT_S = NSIMD / 4, CNT_T = E - NSIMD;          // A: elements per row of a SIMD chain / of the tail chain
+    static constexpr int NG = NSIMD / 8;                                // b: items per row of a SIMD chain (tail: CNT_T)
+    static constexpr int LEN_A = up4(W * (CNT_S > CNT_T ? CNT_S : CNT_T)), LEN_B = up4(W * (NG > CNT_T ? NG : CNT_T));   // array stride of a chain
+    static constexpr int INTS = up4(2 * W * E);                         // [x | y][row][e] integers (A uses the first half)
+    static constexpr int FLOATS = 15 * LEN_A > 10 * LEN_B ? 15 * LEN_A : 10 * LEN_B;   // chain arrays [sum][chain 0..4][LEN]; A's and b's never live together
+    static constexpr int LDS_INTS = INTS + FLOATS;
 };
 __device__ __forceinline__ float lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// acc + arr[LO] + arr[LO + 1] + ... + arr[HI - 1], one rounding per addition, in that order.  arr is 16-byte aligned: single reads
+// up to the first multiple of four, ds_read_b128 from there, single reads for the rest.  The 4-element groups are unrolled four at
+// a time, not completely: a fully unrolled body lets the scheduler hoist every load, and spill.
+template <int LO, int HI>
+__device__ __forceinline__ float fs_chain_range(const float* __restrict__ arr, float acc) {
+    constexpr int A0 = (LO + 3) & ~3, A1 = HI & ~3;
+    if constexpr (A0 >= A1) {
+#pragma unroll
+        for (int i = LO; i < HI; i++) acc = acc + arr[i];
+    } else {
+#pragma unroll
+        for (int i = LO; i < A0; i++) acc = acc + arr[i];
+#pragma unroll 4
+        for (int q = A0 / 4; q < A1 / 4; q++) {
+            const float4 v = reinterpret_cast<const float4*>(arr)[q];
+            acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
+        }
+#pragma unroll
+        for (int i = A1; i < HI; i++) acc = acc + arr[i];
+    }
+    return acc;
+}
+// One chain lane: the SIMD chains hold LS elements, the tail chain LT; every lane walks max(LS, LT) elements (what lies behind a
+// shorter chain's end is stale but inside the chain's array) and keeps a snapshot at min(LS, LT): no per-element select.
+template <int LS, int LT>
+__device__ __forceinline__ float fs_chain(const float* __restrict__ arr, bool is_tail) {
+    constexpr int MINL = LS < LT ? LS : LT, MAXL = LS < LT ? LT : LS;
+    const float snap = fs_chain_range<0, MINL>(arr, 0.f);
+    const float acc = fs_chain_range<MINL, MAXL>(arr, snap);
+    return (is_tail == (LT >= LS)) ? acc : snap;
+}
 
 // lds[row * E + e] = (ix & 0xFFFF) | (iy << 16).  Chain lanes: lane = which * 8 + c, which = 0 (A11), 1 (A12), 2 (A22), c = 0..3
 // the SIMD float lanes, c = 4 the scalar tail.  Returns the three sums (identical in every lane).
 template <int W, int CN>
-__device__ __forceinline__ void fs_sum_A(const int* __restrict__ lds, float (&As)[3]) {
+__device__ __forceinline__ void fs_sum_A(int* __restrict__ lds, float (&As)[3]) {
     using F = LkFs<W, CN>;
-    const int lane = threadIdx.x & 63, c = lane & 7, which = lane >> 3;
-    const int e0 = c < 4 ? c : F::NSIMD, stride = c < 4 ? 4 : 1;
-    const int cnt = (which < 3) ? (c < 4 ? F::CNT_S : (c == 4 ? F::CNT_T : 0)) : 0;
-    // Branch-free: every lane reads MAXC elements per row (indices beyond its count re-read its first element, always a valid
-    // address) and a select keeps the running sum where the element does not count — per-element exec-mask branches made every
-    // LDS read wait for the one before it (measured: the mode's LK time 13.8 -> see DESIGN.md).
-    int off[F::MAXC]; bool on[F::MAXC];
+    float* __restrict__ fl = reinterpret_cast<float*>(lds + F::INTS);
+    const int lane = threadIdx.x & 63;
+    // convert: lane -> (sum, row); element e < NSIMD is item e / 4 of its row in SIMD chain e & 3, the others go to the tail chain
+    for (int it = lane; it < 3 * W; it += 64) {
+        const int which = it / W, y = it - which * W;
+        const int* __restrict__ rp = lds + y * F::E;
+        float* __restrict__ dS = fl + which * (5 * F::LEN_A) + y * F::CNT_S;
+        float* __restrict__ dT = fl + (which * 5 + 4) * F::LEN_A + y * F::CNT_T;
 #pragma unroll
-    for (int i = 0; i < F::MAXC; i++) { on[i] = i < cnt; off[i] = e0 + (on[i] ? i * stride : 0); }
-    float acc = 0.f;
-#pragma unroll FS_UNROLL
-    for (int y = 0; y < W; y++) {
-        const int* rp = lds + y * F::E;
-        int v[F::MAXC];
-#pragma unroll
-        for (int i = 0; i < F::MAXC; i++) v[i] = rp[off[i]];
-#pragma unroll
-        for (int i = 0; i < F::MAXC; i++) {
-            const float fx = (float)(short)(v[i] & 0xFFFF), fy = (float)(v[i] >> 16);
+        for (int e = 0; e < F::E; e++) {
+            const int v = rp[e];
+            const float fx = (float)(short)(v & 0xFFFF), fy = (float)(v >> 16);
             const float a = which == 2 ? fy : fx, b = which == 0 ? fx : fy;
-            const float nacc = a * b + acc;                              // two roundings (the file is built with -ffp-contract=off)
-            acc = on[i] ? nacc : acc;
+            const float p = a * b;                                       // rounded here, added in the chain: v_muladd unfused (this file is built with -ffp-contract=off)
+            if (e < F::NSIMD) dS[(e & 3) * F::LEN_A + (e >> 2)] = p; else dT[e - F::NSIMD] = p;
         }
     }
+    __syncthreads();
+    const int c = lane & 7, which = lane >> 3;
+    const float acc = fs_chain<W * F::CNT_S, W * F::CNT_T>(fl + ((which < 3 ? which : 2) * 5 + (c < 4 ? c : 4)) * F::LEN_A, c >= 4);
 #pragma unroll
     for (int sidx = 0; sidx < 3; sidx++) {
         const float q0 = lane_f(acc, sidx * 8), q1 = lane_f(acc, sidx * 8 + 1), q2 = lane_f(acc, sidx * 8 + 2), q3 = lane_f(acc, sidx * 8 + 3);
@@ -336,29 +370,27 @@ __device__ __forceinline__ void fs_sum_A(const int* __restrict__ lds, float (&As
 }
 // lds[xy * W * E + row * E + e] = diff * Ix (xy = 0) or diff * Iy (xy = 1), exact int32.  Chain lanes: lane = xy * 8 + c.
 template <int W, int CN>
-__device__ __forceinline__ void fs_sum_b(const int* __restrict__ lds, float& b1, float& b2) {
+__device__ __forceinline__ void fs_sum_b(int* __restrict__ lds, float& b1, float& b2) {
     using F = LkFs<W, CN>;
-    const int lane = threadIdx.x & 63, c = lane & 7, xy = lane >> 3;
-    const int cnt = (xy < 2) ? (c < 4 ? F::NG : (c == 4 ? F::CNT_T : 0)) : 0;
-    const int e0 = c < 4 ? c : F::NSIMD, stride = c < 4 ? 8 : 1;
-    const int* P = lds + (xy & 1) * (W * F::E);
-    const bool paired = c < 4;                                           // v_dotprod: element k with element k + 4, exact
-    int off[F::MAXB], off2[F::MAXB]; bool on[F::MAXB];
+    float* __restrict__ fl = reinterpret_cast<float*>(lds + F::INTS);
+    const int lane = threadIdx.x & 63;
+    // convert: lane -> (x | y, row).  v_dotprod pairs element 8g + k with 8g + k + 4 as an exact int32: item g of SIMD chain k
+    if (lane < 2 * W) {
+        const int xy = lane >= W ? 1 : 0, y = lane - xy * W;
+        const int* __restrict__ rp = lds + xy * (W * F::E) + y * F::E;
+        float* __restrict__ dS = fl + xy * (5 * F::LEN_B) + y * F::NG;
+        float* __restrict__ dT = fl + (xy * 5 + 4) * F::LEN_B + y * F::CNT_T;
 #pragma unroll
-    for (int i = 0; i < F::MAXB; i++) { on[i] = i < cnt; off[i] = e0 + (on[i] ? i * stride : 0); off2[i] = off[i] + ((paired && on[i]) ? 4 : 0); }
-    float acc = 0.f;
-#pragma unroll FS_UNROLL
-    for (int y = 0; y < W; y++) {
-        const int* rp = P + y * F::E;
-        int v[F::MAXB], v2[F::MAXB];
+        for (int g = 0; g < F::NG; g++) {
 #pragma unroll
-        for (int i = 0; i < F::MAXB; i++) { v[i] = rp[off[i]]; v2[i] = rp[off2[i]]; }
-#pragma unroll
-        for (int i = 0; i < F::MAXB; i++) {
-            const float nacc = acc + (float)(v[i] + (paired ? v2[i] : 0));
-            acc = on[i] ? nacc : acc;
+            for (int k = 0; k < 4; k++) dS[k * F::LEN_B + g] = (float)(rp[8 * g + k] + rp[8 * g + k + 4]);
         }
+#pragma unroll
+        for (int t = 0; t < F::CNT_T; t++) dT[t] = (float)rp[F::NSIMD + t];
     }
+    __syncthreads();
+    const int c = lane & 7, xy = lane >> 3;
+    const float acc = fs_chain<W * F::NG, W * F::CNT_T>(fl + ((xy < 2 ? xy : 1) * 5 + (c < 4 ? c : 4)) * F::LEN_B, c >= 4);
     const float x0 = lane_f(acc, 0), x1 = lane_f(acc, 1), x2 = lane_f(acc, 2), x3 = lane_f(acc, 3), xt = lane_f(acc, 4);
     const float y0 = lane_f(acc, 8), y1 = lane_f(acc, 9), y2 = lane_f(acc, 10), y3 = lane_f(acc, 11), yt = lane_f(acc, 12);
     b1 = xt + ((x0 + x2) + (x1 + x3));
@@ -824,7 +856,7 @@ template <int W, int G, int CN, bool FS> constexpr int lk_min_waves() { return (
 template <int W, int G, int CN, bool FS = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(1, 64), amdgpu_waves_per_eu(LK_MIN_WAVES(W, G, CN, FS)))) void k_lk_chain(DevBuffers d, int slots, int mode, int chunk, int early_out) {
     constexpr int FPW = 64 / G;                                       // features per wave (= per block)
-    __shared__ int fs_lds[FS ? LkFs<W, CN>::LDS_INTS : 1];            // float-sums mode only (the default build uses no LDS)
+    __shared__ __attribute__((aligned(16))) int fs_lds[FS ? LkFs<W, CN>::LDS_INTS : 1];            // float-sums mode only (the default build uses no LDS)
     int seq, fb;
     if (mode == LK_MAP_AFFINE) {
         const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
