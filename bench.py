@@ -129,6 +129,9 @@ def main():
                     help="BASELINE.json configs[1] (the metric's configuration, default) / configs[2] / configs[4]; the others are extra measurements")
     ap.add_argument("--float-sums", type=int, default=0, help="1 = svo_config.lk_float_sums (LK sums in float in OpenCV's SIMD128 lane order: the mode that "
                     "reproduces the reference's recording digit for digit; several times slower in LK).  An extra measurement, not the bench line")
+    ap.add_argument("--float-sums-steps", type=int, default=10, help="steps of the extra leg that re-times the SAME workload with lk_float_sums = 1 (the mode whose "
+                    "output is the reference's own rounding) on rank 0 after the timed region -> float_sums_mode in the line; skipped when 0, when the line itself "
+                    "is a float-sums run, and when --cpu-frames is 0 (the profiling runs: their counter passes must only see the default kernels)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
@@ -382,6 +385,47 @@ def main():
                              "reference's pipeline and of the OpenCV 4.5 calls it makes, NOT OpenCV itself (absent from the image) — built %s, "
                              "OpenMP over the points of each LK pass and over image rows (the LK inner loops are auto-vectorised by gcc), %d threads; single thread: %.2f frame-pairs/s"
                              % (args.cpu_frames, orc_build, cores, single)}
+        # the same workload in the mode that reproduces the reference's recording digit for digit (svo_config.lk_float_sums: LK
+        # sums in float in OpenCV's SIMD128 lane order) — an extra figure next to `value`, never `value`: rank 0,
+        # its own GPU, fresh contexts, same sequences / contexts / frames in flight, after everything timed above
+        fs_leg = None
+        if args.float_sums_steps > 0 and args.cpu_frames > 0 and not args.float_sums:
+            for v in vos:
+                v.close()
+            fvos = []
+            for c in range(C):
+                v = api.BatchVisualOdometry(W, H, Bc, api.default_config(**dict(over, lk_float_sums=1)), device=local_rank)
+                v.initalize_projection_matricies(Pl, Pr); v.set_stage_timing(True); fvos.append(v)
+            fs_lk, fs_ok = [], []
+
+            def frun(first, count, record):
+                sub = col = 0
+                while col < count:
+                    while sub < count and sub - col < depth:
+                        for c, vo in enumerate(fvos):
+                            lp, rp = ptrs(first + sub, c)
+                            vo.submit_device(lp, rp, W)
+                        sub += 1
+                    for vo in fvos:
+                        ok, _ = vo.collect()
+                        if record:
+                            fs_lk.append(vo.last_timing()[0]); fs_ok.append(float(ok.mean()))
+                    col += 1
+
+            frun(0, 3, False)
+            torch.cuda.synchronize()
+            f0 = time.perf_counter()
+            frun(3, args.float_sums_steps, True)
+            torch.cuda.synchronize()
+            fdt = time.perf_counter() - f0
+            fs_leg = {"value": B * args.float_sums_steps / fdt, "unit": "frame-pairs/s", "n_gpus": 1, "steps": args.float_sums_steps, "warmup": 2,
+                      "ms_per_step": fdt / args.float_sums_steps * 1e3, "lk_kernel_avg_ms": float(np.mean(fs_lk)), "pose_ok_fraction": float(np.mean(fs_ok)),
+                      "what": "the same workload, sequences per GPU and contexts with svo_config.lk_float_sums = 1 (LK normal equations summed in float in "
+                              "the lane order of OpenCV's SIMD128 code: the mode in which the oracle prints 127 of the 128 rows of the reference's run1/result.csv "
+                              "digit for digit and the HIP path equals the oracle bit for bit); rank 0's GPU, outside the timed region; `value` above is the "
+                              "default exact-integer mode"}
+            for v in fvos:
+                v.close()
         # ATE (the second half of BASELINE.json's metric), outside the timed region: slot 0's pose stream over the timed steps,
         # integrated as frame_pose = frame_pose * T (main.cpp:396), against the renderer's ground truth for the same frame
         # transitions and against the CPU oracle on the steps its bounded sample covers
@@ -440,7 +484,7 @@ def main():
                          "algorithmic_bytes_per_frame_pair": {"lk_chain": bytes_lk, "whole_frame": bytes_total},
                          "kernel_avg_ms": lk_avg_ms, "frame_avg_ms": float(np.mean(fr_ms)),
                          "whole_frame_frac": bytes_total * value / world / 1e9 / PEAK_HBM_GBS},
-            "cpu_baseline": cpu, "ate": ate,
+            "cpu_baseline": cpu, "ate": ate, "float_sums_mode": fs_leg,
             "per_rank_value": per_rank_value, "per_rank_lk_kernel_avg_ms": lk_avg_ms_ranks,
             # the line's own proof that the device worked through the timed region (an smi sampler misses a region this short):
             # the LK launches' HIP-event durations of rank 0, summed, against rank 0's wall clock; launches of different contexts

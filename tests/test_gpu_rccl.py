@@ -95,6 +95,9 @@ def test_bench_two_ranks_end_to_end_on_one_gpu_gloo():
     cpu = line["cpu_baseline"]
     assert cpu is not None and cpu["value"] > 0 and cpu["kind"] == "port" and "opencv" in cpu
     assert line["ate"]["long_run"]["frames"] == 3 and line["ate"]["long_run"]["frames_with_identical_flags_and_counters"] == 4
+    # the extra leg in the reference's own LK rounding (lk_float_sums = 1): rank 0's GPU, after the timed region
+    fs = line["float_sums_mode"]
+    assert fs is not None and fs["value"] > 0 and fs["n_gpus"] == 1 and fs["pose_ok_fraction"] > 0.9 and fs["lk_kernel_avg_ms"] > 0
 
 
 # ---------------------------------------------------------------------------- the C entry of the exchange (libsvo_rccl.so)
