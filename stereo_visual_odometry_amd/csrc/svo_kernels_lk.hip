@@ -304,35 +304,46 @@ template <int W, int CN> struct LkFs {
 };
 __device__ __forceinline__ float lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
-// acc + arr[LO] + arr[LO + 1] + ... + arr[HI - 1], one rounding per addition, in that order.  arr is 16-byte aligned: single reads
-// up to the first multiple of four, ds_read_b128 from there, single reads for the rest.  The 4-element groups are unrolled four at
-// a time, not completely: a fully unrolled body lets the scheduler hoist every load, and spill.
-template <int LO, int HI>
-__device__ __forceinline__ float fs_chain_range(const float* __restrict__ arr, float acc) {
-    constexpr int A0 = (LO + 3) & ~3, A1 = HI & ~3;
-    if constexpr (A0 >= A1) {
-#pragma unroll
-        for (int i = LO; i < HI; i++) acc = acc + arr[i];
-    } else {
-#pragma unroll
-        for (int i = LO; i < A0; i++) acc = acc + arr[i];
-#pragma unroll 4
-        for (int q = A0 / 4; q < A1 / 4; q++) {
-            const float4 v = reinterpret_cast<const float4*>(arr)[q];
-            acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
-        }
-#pragma unroll
-        for (int i = A1; i < HI; i++) acc = acc + arr[i];
-    }
-    return acc;
-}
-// One chain lane: the SIMD chains hold LS elements, the tail chain LT; every lane walks max(LS, LT) elements (what lies behind a
-// shorter chain's end is stale but inside the chain's array) and keeps a snapshot at min(LS, LT): no per-element select.
+// One chain lane: acc = 0 + arr[0] + arr[1] + ..., one rounding per addition, in that order.  The SIMD chains hold LS elements, the
+// tail chain LT; every lane walks max(LS, LT) elements (what lies behind a shorter chain's end is stale but inside the chain's
+// array, whose stride is a multiple of four) and keeps a snapshot at min(LS, LT): no per-element select.  arr is 16-byte aligned
+// and read with ds_read_b128, software-pipelined in blocks of FS_BLOCK reads: the next block is requested before the current one
+// is added.  A rolled loop had every eight additions wait for an LDS round trip (LK 4.83 ms per 32-sequence launch against 4.27
+// in this form, same box); completely unrolled without the fences the compiler hoists every read (155 registers).
+#ifndef FS_BLOCK
+#define FS_BLOCK 4
+#endif
 template <int LS, int LT>
 __device__ __forceinline__ float fs_chain(const float* __restrict__ arr, bool is_tail) {
     constexpr int MINL = LS < LT ? LS : LT, MAXL = LS < LT ? LT : LS;
-    const float snap = fs_chain_range<0, MINL>(arr, 0.f);
-    const float acc = fs_chain_range<MINL, MAXL>(arr, snap);
+    constexpr int NQ = (MAXL + 3) / 4, BQ = NQ >= 16 ? FS_BLOCK : 2, NB = (NQ + BQ - 1) / BQ;   // short chains (small windows): two reads in flight are enough, and the registers keep a wave more resident
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(arr);
+    float acc = 0.f, snap = 0.f;
+    float4 buf[2][BQ];
+#pragma unroll
+    for (int k = 0; k < BQ; k++) if (k < NQ) buf[0][k] = p[k];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        if (b + 1 < NB) {
+#pragma unroll
+            for (int k = 0; k < BQ; k++) if ((b + 1) * BQ + k < NQ) buf[(b + 1) & 1][k] = p[(b + 1) * BQ + k];
+        }
+        // the next block's reads are issued BEFORE this block's additions: the fence keeps the reads in front of it, the additions
+        // depend on its output, and the scheduling barrier keeps the machine scheduler from undoing either
+        asm volatile("" : "+v"(acc) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < BQ; k++) {
+            const float4 v = buf[b & 1][k];
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = (b * BQ + k) * 4 + r;
+                if (i < MAXL) acc = acc + e[r];
+                if (i + 1 == MINL) snap = acc;
+            }
+        }
+    }
     return (is_tail == (LT >= LS)) ? acc : snap;
 }
 

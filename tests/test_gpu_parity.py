@@ -326,6 +326,32 @@ def test_odd_window_in_the_frame_pipeline(api):
         assert ok_g, (win, cn)
 
 
+def test_float_sums_mode_window_shapes_gray_and_bgr(api):
+    """Float-sums mode over the shapes its chain layout distinguishes (E = W * CN elements per window row, 8 per SIMD step):
+    no SIMD part at all (E < 8), no scalar tail (E % 8 == 0), tail longer / shorter than a SIMD lane's share, 3-channel rows —
+    through the whole stereo_callback against the oracle, everything a frame produces bit-exact."""
+    from stereo_visual_odometry_amd import synthetic as syn
+    cal = dict(syn.KITTI00, width=320, height=160, cx=160.0, cy=80.0)
+    seq = syn.StereoSequence(cal=cal, n_frames=3, seed=78, step=0.3)
+    Pl, Pr = syn.projection_matrices(cal)
+    for win, cn in ((5, 1), (16, 1), (24, 1), (29, 1), (6, 3), (8, 3), (13, 3), (21, 3)):
+        over = dict(win_w=win, win_h=win, max_level=2, max_translation_norm=2.0, channels=cn, lk_float_sums=1)
+        g = api.VisualOdometry(cfg=api.default_config(**over)); g.initalize_projection_matricies(Pl, Pr)
+        o = orc.VisualOdometry(orc.default_config(**over)); o.initalize_projection_matricies(Pl, Pr)
+        for k in range(3):
+            L, R = seq.left[k], seq.right[k]
+            if cn == 3:
+                L = np.ascontiguousarray(np.stack([L, np.roll(L, 1, 0), 255 - L], -1)); R = np.ascontiguousarray(np.stack([R, np.roll(R, 1, 0), 255 - R], -1))
+            ok_g, T_g = g.stereo_callback(L, R); ok_o, T_o = o.stereo_callback(L, R)
+            assert ok_g == ok_o and g.stats.as_dict() == {f[0]: getattr(o.stats, f[0]) for f in o.stats._fields_}, (win, cn, k)
+            assert np.array_equal(bits(g.features()[0]), bits(o.features()[0])) and np.abs(T_g - T_o).max() < 1e-6, (win, cn, k)
+            if k > 0:
+                to, tg = o.last_tracks(), g.last_tracks()
+                for key in ("pl0", "pr0", "pl1", "pr1"):
+                    assert np.array_equal(bits(to[key]), bits(tg[key])), (win, cn, k, key)
+        assert g.stats.n_into_lk > 50, (win, cn)
+
+
 def test_lk_flat_image_fails_min_eig(api):
     a = np.full((100, 120), 77, np.uint8)
     pts = lk_points(120, 100, 40, 3)
