@@ -308,7 +308,7 @@ __device__ __forceinline__ float lane_f(float v, int lane) { return __int_as_flo
 // tail chain LT; every lane walks max(LS, LT) elements (what lies behind a shorter chain's end is stale but inside the chain's
 // array, whose stride is a multiple of four) and keeps a snapshot at min(LS, LT): no per-element select.  arr is 16-byte aligned
 // and read with ds_read_b128, software-pipelined in blocks of FS_BLOCK reads: the next block is requested before the current one
-// is added.  A rolled loop had every eight additions wait for an LDS round trip (LK 4.83 ms per 32-sequence launch against 4.27
+// is added.  A rolled loop had every eight additions wait for an LDS round trip (LK 4.82 ms per 32-sequence launch against 4.17
 // in this form, same box); completely unrolled without the fences the compiler hoists every read (155 registers).
 #ifndef FS_BLOCK
 #define FS_BLOCK 4

@@ -7,9 +7,9 @@ def load(p):
 L = load('tests/golden/run1_bgr_left_0_47.npy.xz'); R = load('tests/golden/run1_bgr_right_0_47.npy.xz')
 print(L.shape, L.dtype)
 P = np.array([[320., 0, 256, 0], [0, 320, 144, 0], [0, 0, 1, 0]], np.float32); Pr = P.copy(); Pr[0, 3] = -32.0
-for mode in ('bgr', 'gray'):
-    vo = api.VisualOdometry(cfg=api.default_config()); vo.initalize_projection_matricies(P, Pr)
-    fr = (lambda a: a) if mode == 'bgr' else (lambda a: np.ascontiguousarray(a[..., 1]))
+for mode in ('bgr', 'gray', 'bgr, float sums (the reference\'s own LK rounding)'):
+    vo = api.VisualOdometry(cfg=api.default_config(lk_float_sums=1 if 'float' in mode else 0)); vo.initalize_projection_matricies(P, Pr)
+    fr = (lambda a: a) if mode.startswith('bgr') else (lambda a: np.ascontiguousarray(a[..., 1]))
     for k in range(8): vo.stereo_callback(fr(L[k]), fr(R[k]))
     t0 = time.perf_counter(); n = 0
     for rep in range(3):
