@@ -63,8 +63,8 @@ typedef struct {
                                            * 1: they are summed in FLOAT in the lane order of OpenCV 4.x's SIMD128 code (lkpyramid.cpp,
                                            * `#if CV_SIMD128 && !CV_NEON`), i.e. with OpenCV's own rounding.  Measured on the reference's
                                            * recording: mode 1 reproduces run1/result.csv digit for digit (with channels = 3), mode 0 flips
-                                           * borderline tracks at 4 of its first 24 frames (1e-5 .. 1e-3 m).  Several times slower in
-                                           * LK (serial float chains); frame pipeline and svo_circular_matching only. */
+                                           * borderline tracks at 4 of its first 24 frames (1e-5 .. 1e-3 m).  2.4 times the default's LK
+                                           * time at the 21x21 window (the float chains are serial); frame pipeline and svo_circular_matching only. */
 } svo_config;
 
 /* Per-frame counters — the numbers the reference prints at vo.cpp:226,239,326,331,365,108-110,128-130. */
