@@ -297,10 +297,16 @@ template <int W, int CN> struct LkFs {
     static constexpr int E = W * CN, NSIMD = (E / 8) * 8;
     static constexpr int CNT_S = NSIMD / 4, CNT_T = E - NSIMD;          // A: elements per row of a SIMD chain / of the tail chain
     static constexpr int NG = NSIMD / 8;                                // b: items per row of a SIMD chain (tail: CNT_T)
-    static constexpr int LEN_A = up4(W * (CNT_S > CNT_T ? CNT_S : CNT_T)), LEN_B = up4(W * (NG > CNT_T ? NG : CNT_T));   // array stride of a chain
-    static constexpr int INTS = up4(2 * W * E);                         // [x | y][row][e] integers (A uses the first half)
-    static constexpr int FLOATS = 15 * LEN_A > 10 * LEN_B ? 15 * LEN_A : 10 * LEN_B;   // chain arrays [sum][chain 0..4][LEN]; A's and b's never live together
-    static constexpr int LDS_INTS = INTS + FLOATS;
+    // chain arrays, per sum: four SIMD chains of SZ_S floats, then the tail chain of SZ_T (multiples of four: 16-byte reads).  Every
+    // chain lane walks up4(max length) elements from its base: a shorter chain's walker runs on into the arrays behind it (stale
+    // data, never used), so only the very last array needs SLACK behind it.  A's arrays start behind A's integers ([row][e]), b's
+    // behind b's ([x | y][row][e]); the two phases never live together and share the block (7.1 KB at W = 21: five blocks per SIMD).
+    static constexpr int LS_A = W * CNT_S, LS_B = W * NG, LT = W * CNT_T;
+    static constexpr int SZS_A = up4(LS_A), SZS_B = up4(LS_B), SZ_T = up4(LT);
+    static constexpr int SUM_A = 4 * SZS_A + SZ_T, SUM_B = 4 * SZS_B + SZ_T;
+    static constexpr int INTS_A = up4(W * E), INTS_B = up4(2 * W * E);
+    static constexpr int TOT_A = INTS_A + 3 * SUM_A + (SZS_A > SZ_T ? SZS_A - SZ_T : 0), TOT_B = INTS_B + 2 * SUM_B + (SZS_B > SZ_T ? SZS_B - SZ_T : 0);
+    static constexpr int LDS_INTS = TOT_A > TOT_B ? TOT_A : TOT_B;
 };
 __device__ __forceinline__ float lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
@@ -309,14 +315,15 @@ __device__ __forceinline__ float lane_f(float v, int lane) { return __int_as_flo
 // array, whose stride is a multiple of four) and keeps a snapshot at min(LS, LT): no per-element select.  arr is 16-byte aligned
 // and read with ds_read_b128, software-pipelined in blocks of FS_BLOCK reads: the next block is requested before the current one
 // is added.  A rolled loop had every eight additions wait for an LDS round trip (LK 4.82 ms per 32-sequence launch against 4.17
-// in this form, same box); completely unrolled without the fences the compiler hoists every read (155 registers).
+// pipelined, same box); completely unrolled without the fences the compiler hoists every read (155 registers).  Blocks of two:
+// blocks of four are 1.4 % faster at equal occupancy but cost 16 registers, and at W = 21 the fifth wave per SIMD (below) is worth more.
 #ifndef FS_BLOCK
-#define FS_BLOCK 4
+#define FS_BLOCK 2
 #endif
 template <int LS, int LT>
 __device__ __forceinline__ float fs_chain(const float* __restrict__ arr, bool is_tail) {
     constexpr int MINL = LS < LT ? LS : LT, MAXL = LS < LT ? LT : LS;
-    constexpr int NQ = (MAXL + 3) / 4, BQ = NQ >= 16 ? FS_BLOCK : 2, NB = (NQ + BQ - 1) / BQ;   // short chains (small windows): two reads in flight are enough, and the registers keep a wave more resident
+    constexpr int NQ = (MAXL + 3) / 4, BQ = FS_BLOCK, NB = (NQ + BQ - 1) / BQ;
     const float4* __restrict__ p = reinterpret_cast<const float4*>(arr);
     float acc = 0.f, snap = 0.f;
     float4 buf[2][BQ];
@@ -352,26 +359,26 @@ __device__ __forceinline__ float fs_chain(const float* __restrict__ arr, bool is
 template <int W, int CN>
 __device__ __forceinline__ void fs_sum_A(int* __restrict__ lds, float (&As)[3]) {
     using F = LkFs<W, CN>;
-    float* __restrict__ fl = reinterpret_cast<float*>(lds + F::INTS);
+    float* __restrict__ fl = reinterpret_cast<float*>(lds + F::INTS_A);
     const int lane = threadIdx.x & 63;
     // convert: lane -> (sum, row); element e < NSIMD is item e / 4 of its row in SIMD chain e & 3, the others go to the tail chain
     for (int it = lane; it < 3 * W; it += 64) {
         const int which = it / W, y = it - which * W;
         const int* __restrict__ rp = lds + y * F::E;
-        float* __restrict__ dS = fl + which * (5 * F::LEN_A) + y * F::CNT_S;
-        float* __restrict__ dT = fl + (which * 5 + 4) * F::LEN_A + y * F::CNT_T;
+        float* __restrict__ dS = fl + which * F::SUM_A + y * F::CNT_S;
+        float* __restrict__ dT = fl + which * F::SUM_A + 4 * F::SZS_A + y * F::CNT_T;
 #pragma unroll
         for (int e = 0; e < F::E; e++) {
             const int v = rp[e];
             const float fx = (float)(short)(v & 0xFFFF), fy = (float)(v >> 16);
             const float a = which == 2 ? fy : fx, b = which == 0 ? fx : fy;
             const float p = a * b;                                       // rounded here, added in the chain: v_muladd unfused (this file is built with -ffp-contract=off)
-            if (e < F::NSIMD) dS[(e & 3) * F::LEN_A + (e >> 2)] = p; else dT[e - F::NSIMD] = p;
+            if (e < F::NSIMD) dS[(e & 3) * F::SZS_A + (e >> 2)] = p; else dT[e - F::NSIMD] = p;
         }
     }
     __syncthreads();
     const int c = lane & 7, which = lane >> 3;
-    const float acc = fs_chain<W * F::CNT_S, W * F::CNT_T>(fl + ((which < 3 ? which : 2) * 5 + (c < 4 ? c : 4)) * F::LEN_A, c >= 4);
+    const float acc = fs_chain<F::LS_A, F::LT>(fl + (which < 3 ? which : 2) * F::SUM_A + (c < 4 ? c : 4) * F::SZS_A, c >= 4);
 #pragma unroll
     for (int sidx = 0; sidx < 3; sidx++) {
         const float q0 = lane_f(acc, sidx * 8), q1 = lane_f(acc, sidx * 8 + 1), q2 = lane_f(acc, sidx * 8 + 2), q3 = lane_f(acc, sidx * 8 + 3);
@@ -383,25 +390,25 @@ __device__ __forceinline__ void fs_sum_A(int* __restrict__ lds, float (&As)[3]) 
 template <int W, int CN>
 __device__ __forceinline__ void fs_sum_b(int* __restrict__ lds, float& b1, float& b2) {
     using F = LkFs<W, CN>;
-    float* __restrict__ fl = reinterpret_cast<float*>(lds + F::INTS);
+    float* __restrict__ fl = reinterpret_cast<float*>(lds + F::INTS_B);
     const int lane = threadIdx.x & 63;
     // convert: lane -> (x | y, row).  v_dotprod pairs element 8g + k with 8g + k + 4 as an exact int32: item g of SIMD chain k
     if (lane < 2 * W) {
         const int xy = lane >= W ? 1 : 0, y = lane - xy * W;
         const int* __restrict__ rp = lds + xy * (W * F::E) + y * F::E;
-        float* __restrict__ dS = fl + xy * (5 * F::LEN_B) + y * F::NG;
-        float* __restrict__ dT = fl + (xy * 5 + 4) * F::LEN_B + y * F::CNT_T;
+        float* __restrict__ dS = fl + xy * F::SUM_B + y * F::NG;
+        float* __restrict__ dT = fl + xy * F::SUM_B + 4 * F::SZS_B + y * F::CNT_T;
 #pragma unroll
         for (int g = 0; g < F::NG; g++) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) dS[k * F::LEN_B + g] = (float)(rp[8 * g + k] + rp[8 * g + k + 4]);
+            for (int k = 0; k < 4; k++) dS[k * F::SZS_B + g] = (float)(rp[8 * g + k] + rp[8 * g + k + 4]);
         }
 #pragma unroll
         for (int t = 0; t < F::CNT_T; t++) dT[t] = (float)rp[F::NSIMD + t];
     }
     __syncthreads();
     const int c = lane & 7, xy = lane >> 3;
-    const float acc = fs_chain<W * F::NG, W * F::CNT_T>(fl + ((xy < 2 ? xy : 1) * 5 + (c < 4 ? c : 4)) * F::LEN_B, c >= 4);
+    const float acc = fs_chain<F::LS_B, F::LT>(fl + (xy < 2 ? xy : 1) * F::SUM_B + (c < 4 ? c : 4) * F::SZS_B, c >= 4);
     const float x0 = lane_f(acc, 0), x1 = lane_f(acc, 1), x2 = lane_f(acc, 2), x3 = lane_f(acc, 3), xt = lane_f(acc, 4);
     const float y0 = lane_f(acc, 8), y1 = lane_f(acc, 9), y2 = lane_f(acc, 10), y3 = lane_f(acc, 11), yt = lane_f(acc, 12);
     b1 = xt + ((x0 + x2) + (x1 + x3));
@@ -858,7 +865,13 @@ __device__ __forceinline__ void lk_chain_feature(const DevBuffers& d, const LkSe
 // Six: the seventh wave's 1 % is paid with 0.5 GB of scratch traffic per launch (every single-feature wave spills at entry).  Other
 // windows keep the compiler's choice (not measured).  Beside 6 x 80 registers none of the other context's f64 kernels fits, so the
 // LkGate chaining (svo_api.hip) switches itself off and the two contexts' LK launches follow each other, each filling the other's tail.
-template <int W, int G, int CN, bool FS> constexpr int lk_min_waves() { return (W == 21 && G == 64 && CN == 1 && !FS) ? 6 : 1; }
+// Float-sums build at W = 21: FIVE waves per SIMD — its LDS (7.1 KB per one-wave block) allows it and the register cap (96) costs
+// 8 dwords of scratch; measured against four waves without scratch: LK 4.13 vs 4.22 ms per 32-sequence launch, 8 190 vs 7 910
+// frame-pairs/s at the default configuration in float-sums mode (same box; -DFS_WAVES21=1 for the A/B).
+#ifndef FS_WAVES21
+#define FS_WAVES21 5
+#endif
+template <int W, int G, int CN, bool FS> constexpr int lk_min_waves() { return (W == 21 && G == 64 && CN == 1) ? (FS ? FS_WAVES21 : 6) : 1; }
 #ifdef LK_EXP_MINWAVES                      // experiments: -DLK_EXP_MINWAVES=<n> overrides the table
 #define LK_MIN_WAVES(W, G, CN, FS) LK_EXP_MINWAVES
 #else
