@@ -191,7 +191,7 @@ static __device__ __forceinline__ void ingest_pyr1_body(const DevBuffers& d, con
     uint8_t* l0 = base + ls.off; uint8_t* dst = base + ld.off;
     constexpr int SW = 2 * PD_TW + 3, SH = 2 * PD_TH + 3;        // 67 x 19 source tile
     __shared__ __attribute__((aligned(4))) uint8_t tile[SH][SW + 1];
-    __shared__ unsigned short hrow[SH][PD_TW];
+    __shared__ __attribute__((aligned(4))) unsigned short hrow[SH][PD_TW];
     const int ox = bx * PD_TW, oy = by * PD_TH;
     const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
     struct __attribute__((packed, aligned(1))) UD { unsigned v; };
@@ -203,9 +203,10 @@ static __device__ __forceinline__ void ingest_pyr1_body(const DevBuffers& d, con
             *reinterpret_cast<unsigned*>(&tile[ty][4 * c]) = v;
         }
         __syncthreads();
-        {   // the block's own 64 x 16 level-0 pixels: one dword per thread
+        {   // the block's own 64 x 16 level-0 pixels: one dword per thread (tile bytes 4c + 2 .. 4c + 5: two aligned LDS dwords, shifted)
             const int ty = threadIdx.x >> 4, c = threadIdx.x & 15;
-            UD u; u.v = (unsigned)tile[ty + 2][4 * c + 2] | ((unsigned)tile[ty + 2][4 * c + 3] << 8) | ((unsigned)tile[ty + 2][4 * c + 4] << 16) | ((unsigned)tile[ty + 2][4 * c + 5] << 24);
+            const unsigned lo = *reinterpret_cast<const unsigned*>(&tile[ty + 2][4 * c]), hi = *reinterpret_cast<const unsigned*>(&tile[ty + 2][4 * c + 4]);
+            UD u; u.v = __builtin_amdgcn_alignbyte(hi, lo, 2);
             *reinterpret_cast<UD*>(l0 + (size_t)(2 * oy + ty) * ls.stride + 2 * ox + 4 * c) = u;
         }
     } else {
@@ -220,18 +221,29 @@ static __device__ __forceinline__ void ingest_pyr1_body(const DevBuffers& d, con
             if (gx < ls.w && gy < ls.h) l0[(size_t)gy * ls.stride + gx] = tile[ty + 2][tx + 2];   // in range: the tile holds the pixel itself
         }
     }
-    for (int i = threadIdx.x; i < SH * PD_TW; i += 256) {
-        int ty = i / PD_TW, x = i - ty * PD_TW;
-        const uint8_t* r = &tile[ty][2 * x];
-        hrow[ty][x] = (unsigned short)(r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4]);
+    // horizontal 1-4-6-4-1 pass, TWO outputs per thread: outputs 2j and 2j + 1 of a row read tile bytes 4j .. 4j + 6 = two aligned
+    // LDS dwords (ten byte reads before), and leave as one dword of hrow
+    for (int i = threadIdx.x; i < SH * (PD_TW / 2); i += 256) {
+        const int ty = i / (PD_TW / 2), j = i - ty * (PD_TW / 2);
+        const unsigned a = *reinterpret_cast<const unsigned*>(&tile[ty][4 * j]), b = *reinterpret_cast<const unsigned*>(&tile[ty][4 * j + 4]);
+        const unsigned r0 = a & 255u, r1 = (a >> 8) & 255u, r2 = (a >> 16) & 255u, r3 = a >> 24, r4 = b & 255u, r5 = (b >> 8) & 255u, r6 = (b >> 16) & 255u;
+        const unsigned h0 = r2 * 6 + (r1 + r3) * 4 + r0 + r4, h1 = r4 * 6 + (r3 + r5) * 4 + r2 + r6;
+        *reinterpret_cast<unsigned*>(&hrow[ty][2 * j]) = h0 | (h1 << 16);
     }
     __syncthreads();
-    {
-        int y = threadIdx.x / PD_TW, x = threadIdx.x - y * PD_TW;
-        int gx = ox + x, gy = oy + y;
+    if (threadIdx.x < PD_TH * (PD_TW / 2)) {   // vertical pass, two outputs per thread: five LDS dwords, one 2-byte store
+        const int y = threadIdx.x / (PD_TW / 2), x = 2 * (threadIdx.x - y * (PD_TW / 2));
+        const int gx = ox + x, gy = oy + y;
         if (gx < ld.w && gy < ld.h) {
-            int v = hrow[2 * y + 2][x] * 6 + (hrow[2 * y + 1][x] + hrow[2 * y + 3][x]) * 4 + hrow[2 * y][x] + hrow[2 * y + 4][x];
-            dst[(size_t)gy * ld.stride + gx] = (uint8_t)((v + 128) >> 8);
+            unsigned q[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) q[k] = *reinterpret_cast<const unsigned*>(&hrow[2 * y + k][x]);
+            const unsigned v0 = (q[2] & 0xFFFFu) * 6 + ((q[1] & 0xFFFFu) + (q[3] & 0xFFFFu)) * 4 + (q[0] & 0xFFFFu) + (q[4] & 0xFFFFu);
+            const unsigned v1 = (q[2] >> 16) * 6 + ((q[1] >> 16) + (q[3] >> 16)) * 4 + (q[0] >> 16) + (q[4] >> 16);
+            uint8_t* o = dst + (size_t)gy * ld.stride + gx;
+            const unsigned b0 = (v0 + 128) >> 8, b1 = (v1 + 128) >> 8;
+            if (gx + 1 < ld.w) *reinterpret_cast<unsigned short*>(o) = (unsigned short)(b0 | (b1 << 8));   // gx is even, rows are 16-byte aligned
+            else o[0] = (uint8_t)b0;
         }
     }
 }
@@ -254,16 +266,26 @@ static __device__ __forceinline__ void pyrdown2_body(const DevBuffers& d, int le
     uint8_t* mid = base + lm.off; uint8_t* dst = base + ld.off;
     constexpr int MW = 2 * P2_TW + 3, MH = 2 * P2_TH + 3;        // 35 x 19 of the middle level
     constexpr int SW = 2 * MW + 3, SH = 2 * MH + 3;              // 73 x 41 of the source level
-    __shared__ uint8_t tile[SH][SW + 3];
+    __shared__ __attribute__((aligned(4))) uint8_t tile[SH][SW + 3];
     __shared__ unsigned short hrow[SH][MW + 1];
     __shared__ uint8_t mtile[MH][MW + 1];
     __shared__ unsigned short hrow2[MH][P2_TW];
     const int ox = bx * P2_TW, oy = by * P2_TH;                  // level l+2
     const int mx0 = 2 * ox - 2, my0 = 2 * oy - 2;                // level l+1
     const int sx0 = 2 * mx0 - 2, sy0 = 2 * my0 - 2;              // level l
-    for (int i = threadIdx.x; i < SW * SH; i += 256) {
-        int ty = i / SW, tx = i - ty * SW;
-        tile[ty][tx] = src[(size_t)reflect101(sy0 + ty, ls.h) * ls.stride + reflect101(sx0 + tx, ls.w)];
+    if (sx0 >= 0 && sy0 >= 0 && sx0 + SW + 3 <= ls.w && sy0 + SH <= ls.h) {
+        // tiles inside the source level (nearly all of them): rows of 19 unaligned dwords instead of 73 reflected byte loads
+        struct __attribute__((packed, aligned(1))) UD { unsigned v; };
+        constexpr int DPR = (SW + 3) / 4;
+        for (int i = threadIdx.x; i < DPR * SH; i += 256) {
+            const int ty = i / DPR, c = i - ty * DPR;
+            *reinterpret_cast<unsigned*>(&tile[ty][4 * c]) = reinterpret_cast<const UD*>(src + (size_t)(sy0 + ty) * ls.stride + sx0 + 4 * c)->v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < SW * SH; i += 256) {
+            int ty = i / SW, tx = i - ty * SW;
+            tile[ty][tx] = src[(size_t)reflect101(sy0 + ty, ls.h) * ls.stride + reflect101(sx0 + tx, ls.w)];
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SH * MW; i += 256) {
@@ -309,23 +331,36 @@ static __device__ __forceinline__ void pyrdown2_body(const DevBuffers& d, int le
 __global__ __launch_bounds__(256) void k_pyrdown2(DevBuffers d, int level, int ahead) { pyrdown2_body(d, level, blockIdx.x, blockIdx.y, blockIdx.z, ahead); }
 
 // k_pad_pyramid: the REFLECT_101 border of every level of the T1 slot — what cv::buildOpticalFlowPyramid's copyMakeBorder leaves
-// around each level (pyrBorder = BORDER_REFLECT_101).  One thread per border pixel: the ring of a level is cut into its top and
-// bottom bands (pad rows of the padded width) and its left and right bands (h rows of pad pixels); pixel (x, y) outside the level
-// takes level(reflect101(y), reflect101(x)) — the same index function the LK kernel's per-byte border path used before the border
-// was materialised, so the values it sees are the same bytes.
+// around each level (pyrBorder = BORDER_REFLECT_101).  Pixel (x, y) outside the level takes level(reflect101(y), reflect101(x)) — the
+// same index function the LK kernel's per-byte border path used before the border was materialised, so the values it sees are the
+// same bytes.  One thread per border DWORD (row starts, the pad and pixel (0, 0) are 4-byte aligned): the ring of a level is cut
+// into its top and bottom bands (pad rows of the padded width) and, per image row, the left band and the right band — the latter
+// from the aligned x at or below the level's width, so up to three pixels of the level itself are rewritten with their own values.
+// The four source bytes of a dword are consecutive ascending (one unaligned dword load) or descending (load + byte swap) except
+// where a dword straddles a fold of a level narrower than the pad: those go byte by byte.  (First version: one thread, one byte
+// load and one byte store per border pixel — 0.39 ms per 512 sequences; the image stream's kernels run in the gap between two LK
+// launches, so their time is whole-job time.)
 __global__ __launch_bounds__(256) void k_pad_pyramid(DevBuffers d, int ahead) {
     const int plane = blockIdx.z % d.CN, sc = blockIdx.z / d.CN;
     const int seq = sc / 2, cam = sc & 1, level = blockIdx.y;
     const LevelInfo L = d.geom.lv[level];
-    const int P = d.geom.pad;
+    const int P = d.geom.pad, w = L.w, h = L.h;
     uint8_t* img = d.pyr + pyr_index(d, seq, ahead ? d.st[seq].slot_next : d.st[seq].slot_t1, cam) + (size_t)plane * d.geom.pyr_bytes + L.off;
-    const int pw = L.w + 2 * P, band = P * pw, side = L.h * P;
-    const int total = 2 * band + 2 * side;
+    const int rowdw = (w + 2 * P + 3) >> 2;                       // dwords of a band row, from x = -P (the last one may reach into the row's stride padding)
+    const int xr0 = w & ~3, ldw = P >> 2, sdw = ldw + ((w + P - xr0 + 3) >> 2);   // left + right dwords of an image row
+    const int band = P * rowdw, total = 2 * band + h * sdw;
+    struct __attribute__((packed, aligned(1))) UD { unsigned v; };
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         int x, y;
-        if (i < 2 * band) { const int j = i < band ? i : i - band; y = j / pw; x = j - y * pw - P; y = i < band ? y - P : L.h + y; }
-        else { const int j = i - 2 * band, k = j < side ? j : j - side; y = k / P; x = k - y * P; x = j < side ? x - P : L.w + x; }
-        img[(ptrdiff_t)y * L.stride + x] = img[(size_t)reflect101(y, L.h) * L.stride + reflect101(x, L.w)];
+        if (i < 2 * band) { const int j = i < band ? i : i - band, r = j / rowdw; x = (j - r * rowdw) * 4 - P; y = i < band ? r - P : h + r; }
+        else { const int j = i - 2 * band; y = j / sdw; const int k = j - y * sdw; x = k < ldw ? 4 * k - P : xr0 + 4 * (k - ldw); }
+        const uint8_t* srow = img + (size_t)reflect101(y, h) * L.stride;
+        const int s0 = reflect101(x, w), s1 = reflect101(x + 1, w), s2 = reflect101(x + 2, w), s3 = reflect101(x + 3, w);
+        unsigned v;
+        if (s1 == s0 + 1 && s2 == s0 + 2 && s3 == s0 + 3) v = reinterpret_cast<const UD*>(srow + s0)->v;
+        else if (s1 == s0 - 1 && s2 == s0 - 2 && s3 == s0 - 3) v = __builtin_bswap32(reinterpret_cast<const UD*>(srow + s3)->v);
+        else v = (unsigned)srow[s0] | ((unsigned)srow[s1] << 8) | ((unsigned)srow[s2] << 16) | ((unsigned)srow[s3] << 24);
+        *reinterpret_cast<unsigned*>(img + (ptrdiff_t)y * L.stride + x) = v;
     }
 }
 static void launch_pad_pyramid_into(const DevBuffers& d, hipStream_t st, int ahead) {
