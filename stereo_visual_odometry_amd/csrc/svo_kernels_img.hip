@@ -179,6 +179,10 @@ __global__ __launch_bounds__(256) void k_pyrdown(DevBuffers d, int level, int ah
 // k_ingest_pyr1: ingest and the first pyrDown in one launch (single-channel contexts).  A block stages the 67 x 19 source tile of
 // its 32 x 8 level-1 outputs straight from the caller's image, writes the 64 x 16 level-0 pixels it owns and the level-1 tile.
 // (bodies take their block coordinates as arguments so that k_front_a / k_front_b below can run two of them in one launch)
+// TW x TH = the block's tile of level 1 (2 TW x 2 TH pixels of level 0).  Lone streams: 32 x 8 (many blocks for one image).  Many-sequence
+// contexts: 64 x 16 — at a thousand images per launch the kernel was bound by block turnover (962 000 blocks of 1 KB of output each:
+// 0.68 ms per 512 sequences = 1.6 TB/s), not by LDS or HBM; four times the work per block and half the halo.
+template <int TW, int TH>
 static __device__ __forceinline__ void ingest_pyr1_body(const DevBuffers& d, const uint8_t* const* srcs, int stride, int begin_frame, int bx, int by, int bz) {
     const int seq = bz >> 1, cam = bz & 1;
     const LevelInfo ls = d.geom.lv[0], ld = d.geom.lv[1];
@@ -189,10 +193,11 @@ static __device__ __forceinline__ void ingest_pyr1_body(const DevBuffers& d, con
     if (begin_frame == 1 && bx == 0 && by == 0 && cam == 0 && threadIdx.x == 0) frame_begin(d.st[seq]);
     uint8_t* base = d.pyr + pyr_index(d, seq, slot, cam);
     uint8_t* l0 = base + ls.off; uint8_t* dst = base + ld.off;
-    constexpr int SW = 2 * PD_TW + 3, SH = 2 * PD_TH + 3;        // 67 x 19 source tile
+    constexpr int SW = 2 * TW + 3, SH = 2 * TH + 3;              // 67 x 19 source tile at 32 x 8
+    static_assert((SW + 1) % 4 == 0 && TW % 2 == 0, "rows of whole dwords");
     __shared__ __attribute__((aligned(4))) uint8_t tile[SH][SW + 1];
-    __shared__ __attribute__((aligned(4))) unsigned short hrow[SH][PD_TW];
-    const int ox = bx * PD_TW, oy = by * PD_TH;
+    __shared__ __attribute__((aligned(4))) unsigned short hrow[SH][TW];
+    const int ox = bx * TW, oy = by * TH;
     const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
     struct __attribute__((packed, aligned(1))) UD { unsigned v; };
     if (sx0 >= 0 && sy0 >= 0 && sx0 + SW + 1 <= ls.w && sy0 + SH <= ls.h) {
@@ -203,8 +208,9 @@ static __device__ __forceinline__ void ingest_pyr1_body(const DevBuffers& d, con
             *reinterpret_cast<unsigned*>(&tile[ty][4 * c]) = v;
         }
         __syncthreads();
-        {   // the block's own 64 x 16 level-0 pixels: one dword per thread (tile bytes 4c + 2 .. 4c + 5: two aligned LDS dwords, shifted)
-            const int ty = threadIdx.x >> 4, c = threadIdx.x & 15;
+        // the block's own 2 TW x 2 TH level-0 pixels, a dword at a time (tile bytes 4c + 2 .. 4c + 5: two aligned LDS dwords, shifted)
+        for (int i = threadIdx.x; i < (TW / 2) * (2 * TH); i += 256) {
+            const int ty = i / (TW / 2), c = i - ty * (TW / 2);
             const unsigned lo = *reinterpret_cast<const unsigned*>(&tile[ty + 2][4 * c]), hi = *reinterpret_cast<const unsigned*>(&tile[ty + 2][4 * c + 4]);
             UD u; u.v = __builtin_amdgcn_alignbyte(hi, lo, 2);
             *reinterpret_cast<UD*>(l0 + (size_t)(2 * oy + ty) * ls.stride + 2 * ox + 4 * c) = u;
@@ -215,24 +221,24 @@ static __device__ __forceinline__ void ingest_pyr1_body(const DevBuffers& d, con
             tile[ty][tx] = src[(size_t)reflect101(sy0 + ty, ls.h) * stride + reflect101(sx0 + tx, ls.w)];
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 2 * PD_TW * 2 * PD_TH; i += 256) {
-            const int ty = i / (2 * PD_TW), tx = i - ty * (2 * PD_TW);
+        for (int i = threadIdx.x; i < 2 * TW * 2 * TH; i += 256) {
+            const int ty = i / (2 * TW), tx = i - ty * (2 * TW);
             const int gx = 2 * ox + tx, gy = 2 * oy + ty;
             if (gx < ls.w && gy < ls.h) l0[(size_t)gy * ls.stride + gx] = tile[ty + 2][tx + 2];   // in range: the tile holds the pixel itself
         }
     }
     // horizontal 1-4-6-4-1 pass, TWO outputs per thread: outputs 2j and 2j + 1 of a row read tile bytes 4j .. 4j + 6 = two aligned
     // LDS dwords (ten byte reads before), and leave as one dword of hrow
-    for (int i = threadIdx.x; i < SH * (PD_TW / 2); i += 256) {
-        const int ty = i / (PD_TW / 2), j = i - ty * (PD_TW / 2);
+    for (int i = threadIdx.x; i < SH * (TW / 2); i += 256) {
+        const int ty = i / (TW / 2), j = i - ty * (TW / 2);
         const unsigned a = *reinterpret_cast<const unsigned*>(&tile[ty][4 * j]), b = *reinterpret_cast<const unsigned*>(&tile[ty][4 * j + 4]);
         const unsigned r0 = a & 255u, r1 = (a >> 8) & 255u, r2 = (a >> 16) & 255u, r3 = a >> 24, r4 = b & 255u, r5 = (b >> 8) & 255u, r6 = (b >> 16) & 255u;
         const unsigned h0 = r2 * 6 + (r1 + r3) * 4 + r0 + r4, h1 = r4 * 6 + (r3 + r5) * 4 + r2 + r6;
         *reinterpret_cast<unsigned*>(&hrow[ty][2 * j]) = h0 | (h1 << 16);
     }
     __syncthreads();
-    if (threadIdx.x < PD_TH * (PD_TW / 2)) {   // vertical pass, two outputs per thread: five LDS dwords, one 2-byte store
-        const int y = threadIdx.x / (PD_TW / 2), x = 2 * (threadIdx.x - y * (PD_TW / 2));
+    for (int i = threadIdx.x; i < TH * (TW / 2); i += 256) {   // vertical pass, two outputs per thread: five LDS dwords, one 2-byte store
+        const int y = i / (TW / 2), x = 2 * (i - y * (TW / 2));
         const int gx = ox + x, gy = oy + y;
         if (gx < ld.w && gy < ld.h) {
             unsigned q[5];
@@ -247,8 +253,20 @@ static __device__ __forceinline__ void ingest_pyr1_body(const DevBuffers& d, con
         }
     }
 }
+#define IG_TW 64
+#define IG_TH 16
+template <int TW, int TH>
 __global__ __launch_bounds__(256) void k_ingest_pyr1(DevBuffers d, const uint8_t* const* srcs, int stride, int begin_frame) {
-    ingest_pyr1_body(d, srcs, stride, begin_frame, blockIdx.x, blockIdx.y, blockIdx.z);
+    ingest_pyr1_body<TW, TH>(d, srcs, stride, begin_frame, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+static void launch_ingest_pyr1(const DevBuffers& d, const uint8_t* const* ptrs, int stride, int begin_frame, hipStream_t st) {
+    if (d.B > SVO_LONE_MAX_SEQ) {
+        dim3 g((d.geom.lv[1].w + IG_TW - 1) / IG_TW, (d.geom.lv[1].h + IG_TH - 1) / IG_TH, d.B * 2);
+        hipLaunchKernelGGL((k_ingest_pyr1<IG_TW, IG_TH>), g, dim3(256), 0, st, d, ptrs, stride, begin_frame);
+    } else {
+        dim3 g((d.geom.lv[1].w + PD_TW - 1) / PD_TW, (d.geom.lv[1].h + PD_TH - 1) / PD_TH, d.B * 2);
+        hipLaunchKernelGGL((k_ingest_pyr1<PD_TW, PD_TH>), g, dim3(256), 0, st, d, ptrs, stride, begin_frame);
+    }
 }
 
 // k_pyrdown2: levels l+1 AND l+2 from level l in one launch.  A block owns a 16 x 8 tile of level l+2, i.e. 32 x 16 of level l+1;
@@ -390,8 +408,7 @@ void launch_pyramid(const DevBuffers& d, hipStream_t st) { launch_pyramid_from(d
 // ingest + all pyramid levels of the T1 slot (vo.cpp:74-75, 200-201): single-channel contexts fuse the ingest with the first level
 void launch_ingest_pyramid(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride, hipStream_t st, bool begin_frame) {
     if (d.CN == 1 && d.geom.nlevels >= 2) {
-        dim3 g((d.geom.lv[1].w + PD_TW - 1) / PD_TW, (d.geom.lv[1].h + PD_TH - 1) / PD_TH, d.B * 2);
-        hipLaunchKernelGGL(k_ingest_pyr1, g, dim3(256), 0, st, d, left_right_dev_ptrs, stride, (int)begin_frame);
+        launch_ingest_pyr1(d, left_right_dev_ptrs, stride, (int)begin_frame, st);
         launch_pyramid_from(d, 2, st);
         launch_pad_pyramid(d, st);
         return;
@@ -417,8 +434,7 @@ bool ingest_ahead_applies(const DevBuffers& d) {
 }
 void launch_ingest_pyramid_ahead(const DevBuffers& d, const uint8_t* const* left_right_dev_ptrs, int stride, hipStream_t st) {
     hipLaunchKernelGGL(k_pick_next, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
-    dim3 g((d.geom.lv[1].w + PD_TW - 1) / PD_TW, (d.geom.lv[1].h + PD_TH - 1) / PD_TH, d.B * 2);
-    hipLaunchKernelGGL(k_ingest_pyr1, g, dim3(256), 0, st, d, left_right_dev_ptrs, stride, 2);
+    launch_ingest_pyr1(d, left_right_dev_ptrs, stride, 2, st);
     launch_pyramid_from(d, 2, st, 1);
     launch_pad_pyramid_into(d, st, 1);
 }
@@ -774,7 +790,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_bucket_emit_strided(DevBuffers
 static_assert(EMIT_THREADS == 256, "k_front_b runs emit blocks beside 256-thread pyramid blocks");
 __global__ __launch_bounds__(256) void k_front_a(DevBuffers d, const uint8_t* const* srcs, int stride, int ax, int ay, int n_a, int fx, int fy, int threshold) {
     const int i = blockIdx.x;
-    if (i < n_a) { ingest_pyr1_body(d, srcs, stride, 1, i % ax, (i / ax) % ay, i / (ax * ay)); return; }
+    if (i < n_a) { ingest_pyr1_body<PD_TW, PD_TH>(d, srcs, stride, 1, i % ax, (i / ax) % ay, i / (ax * ay)); return; }
     const int j = i - n_a;
     fast_body<0>(nullptr, 0, 0, nullptr, d, 0, threshold, j % fx, (j / fx) % fy, j / (fx * fy), fx, fy);
 }
