@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_pyrdown(DevBuffers d, int level, int ah
 }
 
 // ---- fewer launches for the front of a frame (a lone stream is launch-bound there: a 5 us kernel every 4.5 us of host time) ----
-// k_ingest_pyr1: ingest and the first pyrDown in one launch (single-channel contexts).  A block stages the 67 x 19 source tile of
+// k_ingest_pyr1: ingest and the first pyrDown in one launch (single-channel contexts).  A block stages the 67 x 19 source tile (at 32 x 8) of
 // its 32 x 8 level-1 outputs straight from the caller's image, writes the 64 x 16 level-0 pixels it owns and the level-1 tile.
 // (bodies take their block coordinates as arguments so that k_front_a / k_front_b below can run two of them in one launch)
 // TW x TH = the block's tile of level 1 (2 TW x 2 TH pixels of level 0).  Lone streams: 32 x 8 (many blocks for one image).  Many-sequence
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void k_pad_pyramid(DevBuffers d, int ahead) {
 static void launch_pad_pyramid_into(const DevBuffers& d, hipStream_t st, int ahead) {
     const LevelInfo& L0 = d.geom.lv[0];
     const int P = d.geom.pad, ring0 = 2 * P * (L0.w + 2 * P) + 2 * P * L0.h;
-    int gx = (ring0 + 4 * 256 - 1) / (4 * 256); if (gx < 1) gx = 1; if (gx > 64) gx = 64;      // ~4 border pixels per thread at level 0
+    int gx = (ring0 + 4 * 256 - 1) / (4 * 256); if (gx < 1) gx = 1; if (gx > 64) gx = 64;      // ~one border dword per thread at level 0 (the smaller levels stride less)
     hipLaunchKernelGGL(k_pad_pyramid, dim3(gx, d.geom.nlevels, d.B * 2 * d.CN), dim3(256), 0, st, d, ahead);
 }
 void launch_pad_pyramid(const DevBuffers& d, hipStream_t st) { launch_pad_pyramid_into(d, st, 0); }
