@@ -12,6 +12,8 @@ if [ "$2" = "--summarize" ]; then
   cp $(find $O/s256 -name '*kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats_default_2ctx.csv
   cp $(find $O/s1 -name '*kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats_1seq.csv
   cp $(find $O/s1s -name '*kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats_1seq_static.csv
+  [ -d $O/one512 ] && cp $(find $O/one512 -name '*kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats_512seq_1ctx.csv
+  [ -d $O/fs32 ] && cp $(find $O/fs32 -name '*kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats_float_sums.csv && grep '^{"metric"' $O/fs32.log | tail -1 > profiles/${TAG}_bench_32seq_float_sums.json
   cp $O/bench.json profiles/${TAG}_bench.json; cp $O/bench_static.json profiles/${TAG}_bench_static.json
   grep '^{"metric"' $O/s32.log | tail -1 > profiles/${TAG}_bench_32seq_1ctx.json; grep '^{"metric"' $O/s256.log | tail -1 > profiles/${TAG}_bench_default_under_rocprof.json
   cp $O/latency.txt profiles/${TAG}_latency.txt
@@ -28,6 +30,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/s1s -o s1s -- python3
 echo s1 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s256 -o s256 -- $B > $O/s256.log 2>&1
 echo s256 done
+# every kernel's OWN duration at the bench's batch size: one context of 512 sequences, image stream off, nothing overlaps
+SVO_INGEST_AHEAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/one512 -o one512 -- python3 bench.py --steps 10 --warmup 2 --cpu-frames 0 --ate-frames 0 --seqs 512 --contexts 1 > $O/one512.log 2>&1
+# float-sums mode (the reference's own LK rounding), 32 sequences in one context
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/fs32 -o fs32 -- $B --seqs 32 --contexts 1 --float-sums 1 > $O/fs32.log 2>&1
+echo one512 + fs32 done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- $B > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- $B > $O/write.log 2>&1
 echo hbm counters done
